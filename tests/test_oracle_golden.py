@@ -1,0 +1,230 @@
+"""Pins the CPU oracle (oracle/othello_oracle.c) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from stub_eval import stub_probs_values
+
+U64 = np.uint64
+
+
+# ------------------------------------------------------------------------------------- G1 rules
+def test_rules_game_positions(golden):
+    g = golden("g1_rules.npz")
+    pos, meta, gid = g["game_pos"], g["game_meta"], g["game_id"]
+    s, o, legal, flip = pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]
+    move, term, winner, mcount = meta[:, 0], meta[:, 1], meta[:, 2].astype(np.int8), meta[:, 3]
+    assert np.array_equal(ol.legal_batch(s, o), legal)
+    nt = term == 0
+    real = nt & (move < 64)
+    assert np.array_equal(ol.flip_batch(s[real], o[real], move[real]), flip[real])
+    for i in range(len(s)):
+        b = ol.board(s[i], o[i], int(mcount[i]))
+        assert ol.lib().orc_is_terminal(b) == term[i]
+        assert ol.lib().orc_winner(b) == winner[i]
+        if not term[i]:
+            assert ol.lib().orc_make_move(b, int(move[i])) == 1
+            if gid[i + 1] == gid[i]:
+                assert (b.self_board, b.opp_board, b.move_count) == (s[i + 1], o[i + 1], mcount[i + 1])
+            assert b.passed == (1 if move[i] == 64 else 0)
+
+
+def test_rules_crafted_and_random_patterns(golden):
+    g = golden("g1_rules.npz")
+    pos, meta = g["crafted_pos"], g["crafted_meta"]
+    s, o, legal, flip, opp_legal = (pos[:, i] for i in range(5))
+    assert np.array_equal(ol.legal_batch(s, o), legal)
+    assert np.array_equal(ol.legal_batch(o, s), opp_legal)
+    has = meta[:, 0] < 64
+    assert np.array_equal(ol.flip_batch(s[has], o[has], meta[has, 0]), flip[has])
+    for i in range(len(s)):
+        b = ol.board(s[i], o[i])
+        assert ol.lib().orc_is_terminal(b) == meta[i, 1]
+        assert ol.lib().orc_winner(b) == np.int8(meta[i, 2])
+    # SURVEY L2 probes: A1/B1 does not give C1; B2/A2 gives H1 by wrap
+    assert ol.lib().orc_legal(1 << 0, 1 << 1) & (1 << 2) == 0
+    assert ol.lib().orc_legal(1 << 9, 1 << 8) & (1 << 7)
+
+
+def test_rules_invalid_moves_leave_state(golden):
+    g = golden("g1_rules.npz")
+    for (mv, ok, _s, _o, mc, passed), (s, o) in zip(g["invalid"], g["invalid_u64"]):
+        b = ol.board()
+        assert ol.lib().orc_make_move(b, int(mv)) == ok
+        assert (b.self_board, b.opp_board, b.move_count, b.passed) == (s, o, mc, passed)
+
+
+def test_rules_checksum(golden):
+    n, la, fa = (int(x) for x in golden("g1_rules.npz")["checksum"])
+    assert ol.rules_checksum(n) == (la, fa)
+
+
+def test_reference_known_answers():
+    """Known answers restated from the reference's own tests (tests/test_bitboard.py:29-37,60-87)."""
+    b = ol.board()
+    assert ol.legal_list(b) == [19, 26, 37, 44]
+    assert ol.lib().orc_make_move(b, 19) == 1
+    assert (ol.lib().orc_popcount(b.self_board), ol.lib().orc_popcount(b.opp_board)) == (1, 4)
+    assert ol.lib().orc_make_move(b, 19) == 0  # occupied
+
+
+# ------------------------------------------------------------------------------------- G2 tensor
+def test_tensor(golden):
+    g = golden("g2_tensor.npz")
+    for (s, o), t in zip(g["pos"], g["tensor"]):
+        got = ol.tensor(ol.board(s, o))
+        assert got.dtype == np.float32 and got.shape == (3, 8, 8)
+        assert np.array_equal(got, t.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------- G3 search
+@pytest.fixture(scope="module")
+def stub(golden):
+    g = golden("g3_search.npz")
+    table = g["stub_exp"]
+    return g, ol.make_eval(lambda s, o: stub_probs_values(s, o, table))
+
+
+def test_search_visits_values_policy(stub):
+    g, ev = stub
+    for (s, o), (sims, cp, t0), n, w, pi, pr in zip(g["case_pos"], g["case_cfg"], g["visits"],
+                                                     g["value_sum"], g["policy"], g["prior"]):
+        gpi, gn, gw, gpr = ol.search(ol.board(s, o), int(sims), cp / 1000.0,
+                                     0.0 if t0 else 1.0, ev)
+        assert np.array_equal(gn, n), (s, o, sims, cp)
+        assert np.array_equal(gw, w)        # float64 sums, bit for bit
+        assert np.array_equal(gpr, pr)      # float32 priors (numpy pairwise sum order)
+        assert np.array_equal(gpi, pi)
+
+
+def test_search_batch_lockstep(stub):
+    g, ev = stub
+    boards = [ol.board(s, o) for s, o in g["batch_pos"]]
+    pi, _ = ol.search_batch(boards, 50, 1.0, 1.0, ev)
+    assert np.array_equal(pi, g["batch_pi"])
+
+
+def test_best_action_and_evaluations(stub):
+    g, ev = stub
+    for (s, o), a, e in zip(g["best_pos"], g["best_action"], g["evals"]):
+        b = ol.board(s, o)
+        assert ol.lib().orc_best_action(b, 25, 1.0, ev, None) == a
+        out = np.zeros(65, dtype=np.int32)
+        ol.lib().orc_action_evaluations(b, 25, 1.0, ev, None, ol._p(out, ol.C.c_int32))
+        assert np.array_equal(out, e)
+
+
+# ------------------------------------------------------------------------------------- G4 net
+NETS = [(2, 16), (2, 32), (5, 64), (6, 128), (10, 128)]
+
+
+def _planes(pos):
+    return np.stack([ol.tensor(ol.board(s, o)) for s, o in pos])
+
+
+def _golden_net(g, seed, nb, nf):
+    from othello_reinforcement_learning_test_amd.net import OthelloResNet
+    tag = "s%d_%dx%d" % (seed, nb, nf)
+    torch.manual_seed(seed)
+    net = OthelloResNet(nb, nf).eval()
+    if (nb, nf) == (2, 16):   # this one carries perturbed BN statistics: load them
+        net.load_state_dict({k: torch.from_numpy(g[tag + "_sd_" + k]) for k in net.state_dict()})
+    return tag, net
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+def test_net_restatement_same_init_and_outputs(golden, seed):
+    """Our nn.Module has the reference's state_dict keys and, under the same seed, its weights;
+    its forward equals the reference's outputs."""
+    g = golden("g4_net.npz")
+    x = torch.from_numpy(_planes(g["pos"]))
+    for nb, nf in NETS:
+        tag, net = _golden_net(g, seed, nb, nf)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(g[tag + "_keys"])
+        if (nb, nf) != (2, 16):
+            for k, h in zip(g[tag + "_keys"], g[tag + "_sha"]):
+                assert hashlib.sha256(sd[k].numpy().tobytes()).hexdigest() == h, k
+        with torch.no_grad():
+            logp, v = net(x)
+        assert np.allclose(logp.numpy(), g[tag + "_logp"], atol=1e-6)
+        assert np.allclose(v.numpy(), g[tag + "_v"], atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+def test_oracle_cpu_net(golden, seed):
+    g = golden("g4_net.npz")
+    x = _planes(g["pos"])
+    for nb, nf in NETS:
+        tag, net = _golden_net(g, seed, nb, nf)
+        onet = ol.Net(nb, nf, ol.state_dict_blob(net.state_dict()))
+        logp, v = onet.forward(x)
+        assert np.abs(logp - g[tag + "_logp"]).max() < 1e-4   # tolerance of BASELINE.json north_star
+        assert np.abs(v - g[tag + "_v"][:, 0]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------- G5 episodes
+def _torch_eval(net):
+    def fn(s, o):
+        x = torch.from_numpy(np.stack([ol.tensor(ol.board(a, b)) for a, b in zip(s, o)]))
+        with torch.no_grad():
+            logp, v = net(x)
+            return torch.exp(logp).numpy(), v.numpy().reshape(-1)
+    return ol.make_eval(fn)
+
+
+@pytest.mark.parametrize("seed", [42, 43])
+@pytest.mark.parametrize("kind", ["serial", "parallel"])
+def test_episode_streams(golden, kind, seed):
+    """The oracle's worker loops reproduce the reference's (state, pi, z) streams exactly when given
+    the same evaluator (torch CPU forward of the same weights) and numpy's global RNG."""
+    from othello_reinforcement_learning_test_amd.net import OthelloResNet
+    torch.set_num_threads(1)
+    g = golden("g5_episodes.npz")
+    net = OthelloResNet(2, 16).eval()
+    net.load_state_dict({k: torch.from_numpy(g["net_s%d_sd_%s" % (seed, k)]) for k in net.state_dict()})
+    ev = _torch_eval(net)
+    np.random.seed(seed)
+    rng = ol.numpy_rng()
+    n_ep = 2 if kind == "serial" else 4
+    st, pi, z, mv = ol.selfplay(kind, n_ep, 5, 10, ev, rng, parallel_games=4)
+    tag = "%s_s%d" % (kind, seed)
+    assert np.array_equal(st, g[tag + "_state"].astype(np.float32))
+    assert np.array_equal(z, g[tag + "_z"])
+    assert np.array_equal(pi, g[tag + "_pi"])
+    assert sorted(mv.tolist()) == sorted(g[tag + "_moves"].tolist())
+    if kind == "serial":
+        assert np.array_equal(mv, g[tag + "_moves"])
+
+
+# ------------------------------------------------------------------------------------- live _ref
+def test_live_reference_rules_if_present():
+    """When oracle/_ref (the reference's Cython, built unmodified) is importable, cross-check live."""
+    sys.path.insert(0, os.path.join(ol.ROOT, "oracle"))
+    import build_ref
+    if not os.path.exists(build_ref.built_path()) or not os.path.isdir(build_ref.REF):
+        pytest.skip("reference tree / oracle/_ref not present")
+    bb = build_ref.import_reference()
+    rng = np.random.Generator(np.random.PCG64(99))
+    for _ in range(30):
+        b = bb.OthelloBitboard()
+        ob = ol.board()
+        while not b.is_terminal():
+            assert ol.lib().orc_legal(ob.self_board, ob.opp_board) == b.get_legal_moves_bits()
+            mv = b.get_legal_moves()
+            assert mv == ol.legal_list(ob)
+            a = int(mv[rng.integers(len(mv))])
+            assert b.make_move(a) and ol.lib().orc_make_move(ob, a)
+            assert (b.self_board, b.opp_board, b.move_count, int(b.passed)) == (
+                ob.self_board, ob.opp_board, ob.move_count, ob.passed)
+        assert ol.lib().orc_is_terminal(ob) and ol.lib().orc_winner(ob) == b.get_winner()
+        pi = rng.random(65).astype(np.float32)
+        st, ps = ol.symmetries(ob, pi)
+        for k, (rs, rp) in enumerate(b.get_symmetries(pi)):
+            assert np.array_equal(st[k], rs) and np.array_equal(ps[k], rp)
