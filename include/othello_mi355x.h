@@ -1,0 +1,188 @@
+/*
+ * othello_mi355x.h -- C ABI of libothello_mi355x.so: the MI355X (gfx950) self-play hot path of an
+ * AlphaZero Othello trainer.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (Sylphy0052/Othello_Reinforcement_learning_test) has no FFI for this path: its
+ * boundary is a set of duck-typed Python objects.  Each entry point below names
+ * the reference interface it replaces (paths relative to the reference root).  The Python mirror of
+ * those objects lives in the othello_reinforcement_learning_test_amd package and binds this ABI with ctypes;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returning int returns OTH_OK (0) or a negative OTH_E_* code;
+ *     oth_last_error() gives the message (thread-local).  Nothing throws, nothing aborts.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All device work is
+ *     enqueued on it; functions documented as "synchronous" wait for it before returning.
+ *   - pointers marked DEVICE must be device-accessible (hipMalloc / torch.cuda tensors); pointers
+ *     marked HOST are ordinary host memory; ANY accepts both (hipMemcpyDefault).
+ *   - the caller owns every buffer it passes; handles are opaque and freed by their destroy call.
+ *   - there is no CPU fallback: without a gfx950 device every device entry point fails with
+ *     OTH_E_NO_DEVICE.  The single-board host functions (section 1) are host code by nature.
+ */
+#ifndef OTHELLO_MI355X_H
+#define OTHELLO_MI355X_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTH_OK 0
+#define OTH_E_NO_DEVICE (-1)
+#define OTH_E_INVALID (-2)
+#define OTH_E_HIP (-3)
+#define OTH_E_STATE (-4)
+#define OTH_E_UNSUPPORTED (-5)
+
+const char *oth_last_error(void);
+/* 1 if a gfx950 device is usable, else 0 (never fails) */
+int oth_device_available(void);
+const char *oth_version(void);
+
+/* =============================================================================================
+ * 1. Single-board rules (host side of the OthelloBitboard object, src/cython/bitboard.pxd:11-48)
+ * =========================================================================================== */
+typedef struct {
+    uint64_t self_board; /* bitboard.pxd:25 */
+    uint64_t opp_board;  /* bitboard.pxd:26 */
+    int32_t move_count;  /* bitboard.pxd:27 */
+    int32_t passed;      /* bitboard.pxd:28 */
+} oth_board;
+
+void oth_board_reset(oth_board *b);                                    /* bitboard.pyx:52   reset */
+uint64_t oth_legal_moves(uint64_t self_board, uint64_t opp_board);     /* pyx:135/:187 get_legal_moves_bits */
+uint64_t oth_flip_bits(int pos, uint64_t self_board, uint64_t opp_board); /* pyx:116 _get_flip_bits */
+int oth_board_make_move(oth_board *b, int pos);  /* pyx:195 make_move: 1 ok, 0 invalid (state unchanged) */
+int oth_board_is_terminal(const oth_board *b);                         /* pyx:249 is_terminal */
+int oth_board_get_winner(const oth_board *b);                          /* pyx:266 get_winner */
+void oth_board_get_tensor_input(const oth_board *b, float *out192 /*HOST*/); /* pyx:300 get_tensor_input */
+/* pyx:338 get_symmetries: 8 x ((3,8,8) state, (65,) pi) */
+void oth_board_get_symmetries(const oth_board *b, const float *pi65, float *states8x192, float *pis8x65);
+
+/* =============================================================================================
+ * 2. Batched rules on the device (the same functions over arrays of positions; K2 of SURVEY 2)
+ * =========================================================================================== */
+/* legal[i] = get_legal_moves_bits of (self[i], opp[i])                           all DEVICE */
+int oth_legal_moves_batch(const uint64_t *self_b, const uint64_t *opp_b, uint64_t *legal, int64_t n, void *stream);
+/* make_move per position, in place; ok[i] in {0,1}; flips[i] may be NULL.       all DEVICE */
+int oth_make_move_batch(uint64_t *self_b, uint64_t *opp_b, const int32_t *pos, int32_t *ok, uint64_t *flips,
+                        int64_t n, void *stream);
+/* terminal[i] = is_terminal, winner[i] = get_winner                              all DEVICE */
+int oth_status_batch(const uint64_t *self_b, const uint64_t *opp_b, int32_t *terminal, int32_t *winner,
+                     int64_t n, void *stream);
+/* out[i] = get_tensor_input as float32 [n,3,8,8]                                 all DEVICE */
+int oth_tensor_input_batch(const uint64_t *self_b, const uint64_t *opp_b, float *out, int64_t n, void *stream);
+/* rules checksum over the LCG position stream of tests/golden (size-independent parity property) */
+int oth_rules_checksum(int64_t n, uint64_t *legal_acc /*HOST*/, uint64_t *flip_acc /*HOST*/, void *stream);
+
+/* =============================================================================================
+ * 3. Evaluator: OthelloResNet forward (src/model/net.py:139-205), eval mode
+ * =========================================================================================== */
+typedef struct oth_net oth_net;
+#define OTH_PREC_F32 0     /* generic fp32 VALU kernel (any filter count) */
+#define OTH_PREC_F16X3 1   /* MFMA, fp16 hi/lo split of both operands, fp32 accumulate (fp32-equivalent) */
+#define OTH_PREC_F16 2     /* MFMA, single fp16 pass (fast; NOT within the 1e-4 parity tolerance in general) */
+
+/* net.py:157-180 __init__(num_blocks, num_filters, board_size).  board_size must be 8. */
+oth_net *oth_net_create(int num_blocks, int num_filters, int board_size);
+void oth_net_destroy(oth_net *net);
+/* number of float32 values oth_net_load_state expects */
+int64_t oth_net_state_floats(const oth_net *net);
+/* Load weights = model.state_dict() flattened: every floating tensor in registration order
+ * (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, ... fc.weight, fc.bias),
+ * int64 num_batches_tracked skipped.  HOST float32.  BatchNorms are folded (eval mode, L19) and
+ * the weights repacked for the kernels.  Call again whenever the trainer has updated the model. */
+int oth_net_load_state(oth_net *net, const float *blob, int64_t n_floats, int precision);
+/* forward(x) for x given as packed bitboards (self, opp, legal planes of get_tensor_input).
+ * logp: [n,65] log-probabilities, v: [n].  all DEVICE.  n_valid (DEVICE int32*, may be NULL): when
+ * given, only the first *n_valid (<= n) positions are evaluated (device-side batch length). */
+int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *opp_b, const uint64_t *legal,
+                         int64_t n, const int32_t *n_valid, float *logp, float *v, void *stream);
+/* forward(x) for x float32 [n,3,8,8] holding 0/1 planes (the reference's input format) DEVICE */
+int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
+
+/* =============================================================================================
+ * 4. Search + self-play engine
+ *    replaces MCTS (src/mcts/mcts.py:17), MCTSNode (src/mcts/node.py:12), BatchMCTS
+ *    (src/train/parallel_self_play.py:31) and the worker loops (self_play.py:52-163,
+ *    parallel_self_play.py:282-407).
+ * =========================================================================================== */
+typedef struct oth_engine oth_engine;
+
+typedef struct {
+    int32_t max_games;         /* G: concurrent game slots (num_parallel_games, parallel_self_play.py:232) */
+    int32_t num_simulations;   /* mcts.num_simulations */
+    int32_t temperature_threshold; /* self_play.temperature_threshold */
+    float c_puct;              /* python float -> float32 weak scalar at node.py:116 */
+    double dirichlet_alpha;    /* mcts.py:33 */
+    double dirichlet_epsilon;  /* mcts.py:34 */
+    int32_t store_late_onehot; /* 1: SelfPlayWorker semantics (pi stored one-hot after the threshold, L14);
+                                  0: ParallelSelfPlayWorker semantics (always the visit distribution, L15) */
+    int32_t reserved;
+} oth_engine_cfg;
+
+oth_engine *oth_engine_create(const oth_engine_cfg *cfg);
+void oth_engine_destroy(oth_engine *e);
+/* evaluator used by oth_search_run / oth_selfplay_run (not owned) */
+int oth_engine_set_net(oth_engine *e, oth_net *net);
+
+/* ---- step-wise search over n <= max_games root positions (BatchMCTS.search_batch semantics:
+ *      one leaf per game per simulation step).  An external evaluator can be driven through
+ *      leaves()/expand(); the built-in network through oth_search_run. -------------------------- */
+/* roots: HOST arrays self[n], opp[n].  Resets the trees and queues the n roots for evaluation. */
+int oth_search_begin(oth_engine *e, const uint64_t *self_b, const uint64_t *opp_b, int32_t n, void *stream);
+/* select one leaf per game (node.py:91 select_child, parallel_self_play.py:172 _select_leaf);
+ * terminal leaves are backed up at once with float(get_winner()) (mcts.py:127-130). */
+int oth_search_select(oth_engine *e, void *stream);
+/* positions waiting for evaluation after begin/select.  Synchronous.  count: HOST int32;
+ * self/opp/legal: HOST arrays of capacity max_games (may be NULL). */
+int oth_search_leaves(oth_engine *e, int32_t *count, uint64_t *self_b, uint64_t *opp_b, uint64_t *legal, void *stream);
+/* Feed evaluator results for the pending positions, in the order oth_search_leaves gave them, expand
+ * (node.py:62) and back up (mcts.py:152).  policy: ANY float32 [count,65]; is_log=1: log-probs (the
+ * network's output; exp applied as mcts.py:189), 0: probabilities.  value: ANY float32 [count]. */
+int oth_search_expand(oth_engine *e, const float *policy, const float *value, int32_t is_log, void *stream);
+/* begin(already called) + num_simulations x (select, network, expand) with the engine's network */
+int oth_search_run(oth_engine *e, void *stream);
+/* Results per root i.  Synchronous.  Any output may be NULL.  HOST.
+ *   pi[n,65]      node.py:147 get_policy_distribution(temperature); temperature 0 or 1
+ *   visits[n,65]  child visit counts;  value_sum[n,65] child W (float64);  prior[n,65] child P */
+int oth_search_results(oth_engine *e, double temperature, float *pi, int32_t *visits, double *value_sum,
+                       float *prior, void *stream);
+
+/* ---- self-play -------------------------------------------------------------------------------
+ * Plays num_games complete games on the device, max_games at a time with finished slots refilled,
+ * sampling actions with a counter-based RNG keyed by (seed, game id, ply).  add_noise is accepted
+ * for interface parity; Dirichlet noise on root priors cannot change any output of this search
+ * (the root is never backed up, so its exploration term is zero: SURVEY L10/L12).
+ * Synchronous.  Results stay in the engine until the next run; read them with oth_selfplay_fetch. */
+int oth_selfplay_run(oth_engine *e, int32_t num_games, uint64_t seed, int32_t add_noise, int64_t *n_samples /*HOST*/,
+                     void *stream);
+/* Lock-step variant driven ply by ply from the host (reference RNG compatibility: the caller draws
+ * numpy's dirichlet/choice itself).  begin: start n <= max_games games from the initial position. */
+int oth_selfplay_begin(oth_engine *e, int32_t n, void *stream);
+/* search the current positions of all unfinished games (roots + sims with the engine's network);
+ * pi: HOST [n,65] visit distributions (T=1), active: HOST [n] 1 for games that were searched. */
+int oth_selfplay_search(oth_engine *e, float *pi, int32_t *active, void *stream);
+/* record (state, pi, player) and play actions[i] (HOST [n], ignored for finished games) */
+int oth_selfplay_apply(oth_engine *e, const int32_t *actions, int32_t *n_unfinished /*HOST*/, void *stream);
+/* finish a lock-step run: assign z and compact.  n_samples: HOST */
+int oth_selfplay_end(oth_engine *e, int64_t *n_samples, void *stream);
+/* Copy the replay tuples of the last run, game-major then ply order (the order of
+ * parallel_self_play.py:400-405): states [n,3,8,8] f32, pis [n,65] f32, zs [n] f32,
+ * game_len [num_games] int32 (may be NULL).  Destination pointers: ANY.  Synchronous. */
+int oth_selfplay_fetch(oth_engine *e, float *states, float *pis, float *zs, int32_t *game_len, void *stream);
+/* DEVICE pointers to the same compacted arrays (valid until the next run), for on-device consumers
+ * such as the RCCL all-gather: no copy. */
+int oth_selfplay_device_ptrs(oth_engine *e, float **states, float **pis, float **zs, int64_t *n_samples);
+
+/* counters of the last run: [0] network evaluations, [1] simulations, [2] plies, [3] games,
+ * [4] network batches launched, [5] terminal-leaf simulations */
+int oth_engine_counters(oth_engine *e, int64_t out[8]);
+/* timing hook for bench.py: HIP-event time (ms) spent in the network kernel during the last run, and
+ * the number of launches; measured on the stream the kernels ran on */
+int oth_engine_kernel_time(oth_engine *e, double *net_ms, int64_t *net_launches, double *tree_ms, int64_t *tree_launches);
+int oth_engine_set_timing(oth_engine *e, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

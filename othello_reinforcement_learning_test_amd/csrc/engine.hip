@@ -1,0 +1,959 @@
+// engine.hip -- section 4 of include/othello_mi355x.h: PUCT tree search and self-play on the device.
+//
+// Execution model (gfx950): ONE WAVEFRONT PER GAME, LANE = BOARD SQUARE.  A node's children are
+// its legal squares in ascending order (reference node.py:83-87 inserts them in that order), so the
+// 64 lanes of a wave score all children of a node in one pass (float64, as the reference's numpy
+// arithmetic does) and a ballot picks the first maximum.  Bitboards stay in registers while a wave
+// descends; the tree (32-B nodes, 16-B edges) lives in a per-game arena in HBM that is small
+// enough to stay L2/Infinity-Cache resident.  Leaves are appended to a dense evaluation batch
+// (24 B per position: self, opp, legal) that the network kernel consumes without a host round trip.
+//
+// Reference semantics reproduced: L8 expand, L9 select, L10 backup incl. the root
+// never being backed up, L11 terminal leaves, L13 policy from visit counts, L14-L18 worker loops.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "net.h"
+#include "othello_rules.h"
+
+namespace oth {
+
+constexpr int kMaxPly = 128;  // hard bound: <=60 stones placed, no two consecutive passes => <=121 plies
+constexpr int kEdgesPerNode = 60;  // children <= number of empty squares <= 60
+
+struct __attribute__((aligned(16))) Node {  // 32 B
+    uint64_t self_b, opp_b, legal;
+    uint32_t edge_base;
+    uint32_t n_children;
+};
+struct __attribute__((aligned(16))) Edge {  // 16 B: one 128-bit load per lane
+    double w;        // value_sum, python float (node.py:39)
+    float prior;     // np.float32 (node.py:84)
+    uint16_t n;      // visit_count (node.py:38)
+    uint16_t child;  // node index once expanded, 0 = not expanded (the root is never a child)
+};
+
+enum : int32_t { PEND_NONE = 0, PEND_ROOT = 1, PEND_LEAF = 2 };
+
+struct Dev {  // device pointers + scalars handed to every kernel by value
+    int32_t n_slots, cap_nodes, cap_edges, cap_path, num_sims, temp_threshold, store_late_onehot;
+    float c_puct;
+    // per slot
+    uint64_t *g_self, *g_opp;        // current game position
+    int32_t *g_ply, *g_id, *g_active;  // ply counter, game id, slot searching this step
+    Node* nodes;
+    Edge* edges;
+    int32_t *n_nodes, *n_edges;
+    uint32_t* path;
+    int32_t *path_len, *pend, *eval_slot;
+    uint64_t *leaf_self, *leaf_opp, *leaf_legal;
+    // evaluation batch (dense, filled through an atomic cursor)
+    uint64_t *ev_self, *ev_opp, *ev_legal;
+    int32_t* n_eval;
+    float *logp, *val;
+    const double* sqrt_tab;  // sqrt(n) exactly as numpy computes it, n = 0..num_sims+1
+    // self-play bookkeeping
+    int32_t *next_game, *n_active, num_games;
+    uint64_t* hist_bits;   // [num_games][kMaxPly][3]
+    float* hist_pi;        // [num_games][kMaxPly][65]
+    int32_t *game_len, *game_winner;
+    unsigned long long* counters;  // [8]
+    uint64_t seed;
+};
+
+// ---- wave helpers --------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// mcts.py:152-168 / parallel_self_play.py:199-204: child.update(v); v = -v from the leaf upwards.
+// Edges on a path are distinct, so lane i updates path entry i (sign by distance from the leaf).
+// link_child != 0: the leaf edge (path[depth-1]) additionally gets its new child node id, in the same
+// read-modify-write (no second store to that edge from another lane).
+template <typename PathT>
+__device__ __forceinline__ void backup_path(Edge* edges, const PathT* path, int depth, double value, int lane,
+                                            int link_child) {
+    for (int i = lane; i < depth; i += 64) {
+        Edge* e = &edges[path[i]];
+        const double v = ((depth - 1 - i) & 1) ? -value : value;
+        Edge t = *e;
+        t.n = (uint16_t)(t.n + 1);
+        t.w = t.w + v;
+        if (link_child && i == depth - 1) t.child = (uint16_t)link_child;
+        *e = t;
+    }
+}
+
+// queue a position for evaluation; returns the batch slot (lane-uniform; lane 0 does the atomic)
+__device__ __forceinline__ int queue_eval(const Dev& d, uint64_t sb, uint64_t ob, uint64_t lg, int lane) {
+    int slot = 0;
+    if (lane == 0) {
+        slot = atomicAdd(d.n_eval, 1);
+        d.ev_self[slot] = sb;
+        d.ev_opp[slot] = ob;
+        d.ev_legal[slot] = lg;
+        atomicAdd(&d.counters[0], 1ULL);
+    }
+    return __shfl(slot, 0);
+}
+
+// ---- K1a: select (node.py:91-126, parallel_self_play.py:172-197) ----------------------------------
+__global__ __launch_bounds__(256) void k_select(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots || !d.g_active[g]) return;
+    extern __shared__ uint32_t lds_path_all[];  // [4 waves][cap_path]: the path of the current descent
+    volatile uint32_t* lpath = lds_path_all + (threadIdx.x >> 6) * d.cap_path;
+    Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
+    Edge* edges = d.edges + (size_t)g * d.cap_edges;
+    uint32_t* path = d.path + (size_t)g * d.cap_path;
+    int node = 0, pv = 0, depth = 0;
+    uint64_t sb = nodes[0].self_b, ob = nodes[0].opp_b;
+    for (;;) {
+        const Node nd = nodes[node];
+        const bool pass = nd.legal == 0;
+        const bool act = pass ? (lane == 0) : ((nd.legal >> lane) & 1ULL);
+        const int rank = __popcll(nd.legal & ((1ULL << lane) - 1ULL));
+        const int ei = (int)nd.edge_base + rank;
+        double score = -INFINITY;
+        int e_n = 0, e_child = 0;
+        if (act) {
+            const Edge e = edges[ei];
+            e_n = e.n;
+            e_child = e.child;
+            const double q = e.n == 0 ? 0.0 : e.w / (double)e.n;          // node.py:51-60
+            const float cp_p = d.c_puct * e.prior;                       // float32 product (weak python scalar)
+            const double u = (double)cp_p * d.sqrt_tab[pv] / (double)(1 + e.n);  // node.py:116
+            score = q + u;                                               // node.py:119
+        }
+        const double best = wave_max_f64(score);
+        const unsigned long long eq = __ballot(act && score == best);
+        const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
+        const int action = pass ? 64 : L;
+        const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
+        if (lane == 0) lpath[depth] = (uint32_t)ce;
+        ++depth;
+        apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
+        if (child == 0) break;        // that child has no children yet: leaf
+        pv = nvis;
+        node = child;
+    }
+    const uint64_t lg = legal_moves(sb, ob);
+    const bool terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
+    if (lane == 0) atomicAdd(&d.counters[1], 1ULL);
+    __builtin_amdgcn_wave_barrier();
+    if (terminal) {  // parallel_self_play.py:133-135: back up float(get_winner()) immediately
+        backup_path(edges, lpath, depth, (double)winner(sb, ob), lane, 0);
+        if (lane == 0) {
+            d.pend[g] = PEND_NONE;
+            atomicAdd(&d.counters[5], 1ULL);
+        }
+    } else {
+        const int slot = queue_eval(d, sb, ob, lg, lane);
+        for (int i = lane; i < depth; i += 64) path[i] = lpath[i];  // for k_expand (next launch)
+        if (lane == 0) {
+            d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
+            d.path_len[g] = depth;
+            d.eval_slot[g] = slot;
+            d.pend[g] = PEND_LEAF;
+        }
+    }
+}
+
+// ---- K1b: expand + backup (node.py:62-89, mcts.py:133-148) ---------------------------------------
+__global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__ policy,
+                                                const float* __restrict__ value, int is_log) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots) return;
+    const int pend = d.pend[g];
+    if (pend == PEND_NONE) return;
+    const int slot = d.eval_slot[g];
+    const float* pol = policy + (size_t)slot * 65;
+    const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g], legal = d.leaf_legal[g];
+    const bool pass = legal == 0;
+    float p = pol[lane], p64 = pol[64];
+    if (is_log) {  // policy_probs = torch.exp(policy_logits), mcts.py:189
+        p = expf(p);
+        p64 = expf(p64);
+    }
+    // masked_probs[legal] = policy_probs[legal] (node.py:71-72); element 64 is the pass action
+    const bool act = pass ? false : ((legal >> lane) & 1ULL);
+    const float m = act ? p : 0.0f;
+    const float m64 = pass ? p64 : 0.0f;
+    // prob_sum = masked_probs.sum(): numpy float32 pairwise reduction over 65 elements, i.e.
+    // r[j] = a[j] + a[8+j] + ... + a[56+j] (in that order), ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), + a[64]
+    float r = m;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r += __shfl(m, (8 * i + lane) & 63);
+    const float r0 = __shfl(r, 0), r1 = __shfl(r, 1), r2 = __shfl(r, 2), r3 = __shfl(r, 3);
+    const float r4 = __shfl(r, 4), r5 = __shfl(r, 5), r6 = __shfl(r, 6), r7 = __shfl(r, 7);
+    float sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    sum += m64;
+    const int nch = pass ? 1 : __popcll(legal);
+    float prior;
+    if (sum > 0.0f) prior = (pass ? m64 : m) / sum;                  // masked_probs /= prob_sum
+    else prior = (float)(1.0 / (double)nch);                         // node.py:78-80 uniform fallback
+    Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
+    Edge* edges = d.edges + (size_t)g * d.cap_edges;
+    const int id = d.n_nodes[g], base = d.n_edges[g];
+    const bool wr = pass ? (lane == 0) : act;
+    if (wr) {
+        const int rank = __popcll(legal & ((1ULL << lane) - 1ULL));
+        Edge e;
+        e.w = 0.0; e.prior = prior; e.n = 0; e.child = 0;
+        edges[base + rank] = e;
+    }
+    const int depth = pend == PEND_LEAF ? d.path_len[g] : 0;
+    const uint32_t* path = d.path + (size_t)g * d.cap_path;
+    if (lane == 0) {
+        Node nd;
+        nd.self_b = sb; nd.opp_b = ob; nd.legal = legal; nd.edge_base = (uint32_t)base; nd.n_children = (uint32_t)nch;
+        nodes[id] = nd;
+        d.n_nodes[g] = id + 1;
+        d.n_edges[g] = base + nch;
+        d.pend[g] = PEND_NONE;
+    }
+    if (depth > 0) {
+        const double v = (double)value[slot];  // values[j].item(): float32 -> python float
+        backup_path(edges, path, depth, v, lane, id);
+    }
+}
+
+// Philox4x32-10 keyed by (seed), counter (game id, ply): one uniform double in [0,1) per decision
+__device__ inline double philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t x0 = c0, x1 = c1, x2 = 0x2545F491u, x3 = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+        const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    // 53 random bits, the construction numpy's random_sample uses: (a>>5, b>>6)
+    return ((double)(x0 >> 5) * 67108864.0 + (double)(x1 >> 6)) / 9007199254740992.0;
+}
+
+// (re)start the search of slot g from position (sb, ob): empty tree, root queued for evaluation
+__device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uint64_t ob, int lane) {
+    const uint64_t lg = legal_moves(sb, ob);
+    const int slot = queue_eval(d, sb, ob, lg, lane);
+    if (lane == 0) {
+        d.n_nodes[g] = 0;
+        d.n_edges[g] = 0;
+        d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
+        d.path_len[g] = 0;
+        d.eval_slot[g] = slot;
+        d.pend[g] = PEND_ROOT;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __restrict__ sb,
+                                                      const uint64_t* __restrict__ ob, int n) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots) return;
+    if (g >= n) {
+        if (lane == 0) { d.g_active[g] = 0; d.pend[g] = PEND_NONE; }
+        return;
+    }
+    if (lane == 0) { d.g_active[g] = 1; d.g_self[g] = sb[g]; d.g_opp[g] = ob[g]; }
+    begin_root(d, g, sb[g], ob[g], lane);
+}
+
+// start games: slot g gets game id g (or stays idle), ply 0, start position, root queued
+__global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots) return;
+    if (g >= n_start) {
+        if (lane == 0) { d.g_active[g] = 0; d.g_id[g] = -1; d.pend[g] = PEND_NONE; }
+        return;
+    }
+    if (lane == 0) {
+        d.g_active[g] = 1; d.g_id[g] = g; d.g_ply[g] = 0;
+        d.g_self[g] = kStartSelf; d.g_opp[g] = kStartOpp;
+        atomicAdd(d.n_active, 1);
+    }
+    begin_root(d, g, kStartSelf, kStartOpp, lane);
+}
+
+// ---- K4: ply step (node.py:147-182, parallel_self_play.py:374-397, self_play.py:101-117) ---------
+// Per game: pi from root visit counts, record (position, pi), choose the action (sample while
+// ply < threshold, else first argmax), play it, detect the end of the game, refill the slot, and
+// queue the next root.  forced != nullptr: play forced[g] instead (host-driven lock-step mode).
+__global__ __launch_bounds__(256) void k_ply(Dev d, const int32_t* __restrict__ forced, int refill) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots || !d.g_active[g]) return;
+    const Node root = d.nodes[(size_t)g * d.cap_nodes];
+    const Edge* edges = d.edges + (size_t)g * d.cap_edges;
+    const bool pass = root.legal == 0;
+    const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
+    const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
+    int n = act ? (int)edges[root.edge_base + rank].n : 0;
+    const int n64 = pass ? (int)edges[root.edge_base].n : 0;
+    const int total = wave_sum_i32(n) + n64;
+    // counts / counts.sum() in float32 (node.py:175-177 with temperature 1)
+    const float tot_f = (float)total;
+    float pi = act ? (float)n / tot_f : 0.0f;
+    float pi64 = pass ? (float)n64 / tot_f : 0.0f;
+    // first maximum of the visit counts (np.argmax)
+    const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
+    const unsigned long long eqm = __ballot(act && n == best_n);
+    const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+    const int ply = d.g_ply[g], gid = d.g_id[g];
+    const bool sample = ply < d.temp_threshold;
+    int action;
+    if (forced) {
+        action = forced[g];
+    } else if (!sample) {
+        action = amax;
+    } else {
+        // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
+        const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
+        double c = 0.0;
+        double cdf_lane = 0.0;
+        for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
+            c += (double)__shfl(pi, i);
+            if (i == lane) cdf_lane = c;
+        }
+        const double c64 = c + (double)pi64;
+        const unsigned long long gt = __ballot(cdf_lane / c64 > u);
+        action = gt ? (__ffsll(gt) - 1) : 64;
+    }
+    if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
+        pi = (lane == amax) ? 1.0f : 0.0f;
+        pi64 = (amax == 64) ? 1.0f : 0.0f;
+    }
+    // record the sample: position bits (state planes are unpacked at compaction) and pi
+    uint64_t sb = d.g_self[g], ob = d.g_opp[g];
+    {
+        const size_t h = (size_t)gid * kMaxPly + ply;
+        float* hp = d.hist_pi + h * 65;
+        hp[lane] = pi;
+        if (lane == 0) {
+            hp[64] = pi64;
+            d.hist_bits[h * 3 + 0] = sb;
+            d.hist_bits[h * 3 + 1] = ob;
+            d.hist_bits[h * 3 + 2] = root.legal;
+            atomicAdd(&d.counters[2], 1ULL);
+        }
+    }
+    apply_known(sb, ob, action);  // game.board.make_move(action)
+    const int nply = ply + 1;
+    const bool over = is_terminal(sb, ob) || nply >= kMaxPly;
+    if (!over) {
+        if (lane == 0) { d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
+        begin_root(d, g, sb, ob, lane);
+        return;
+    }
+    int new_id = -1;
+    if (lane == 0) {
+        d.game_len[gid] = nply;
+        d.game_winner[gid] = winner(sb, ob);  // relative to the side to move at the end (L16)
+        atomicAdd(&d.counters[3], 1ULL);
+        if (refill) {
+            const int nid = atomicAdd(d.next_game, 1);
+            if (nid < d.num_games) new_id = nid;
+        }
+    }
+    new_id = __shfl(new_id, 0);
+    if (new_id >= 0) {
+        if (lane == 0) { d.g_id[g] = new_id; d.g_ply[g] = 0; d.g_self[g] = kStartSelf; d.g_opp[g] = kStartOpp; }
+        begin_root(d, g, kStartSelf, kStartOpp, lane);
+    } else if (lane == 0) {
+        d.g_active[g] = 0;
+        d.g_id[g] = -1;
+        d.pend[g] = PEND_NONE;
+        atomicSub(d.n_active, 1);
+    }
+}
+
+// ---- search results (node.py:147-182 + root statistics) ------------------------------------------
+__global__ __launch_bounds__(256) void k_results(Dev d, int n, int temp_zero, float* __restrict__ pi_out,
+                                                 int32_t* __restrict__ visits, double* __restrict__ wsum,
+                                                 float* __restrict__ prior) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n) return;
+    const Node root = d.nodes[(size_t)g * d.cap_nodes];
+    const Edge* edges = d.edges + (size_t)g * d.cap_edges;
+    const bool pass = root.legal == 0;
+    const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
+    const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
+    Edge e{0.0, 0.0f, 0, 0}, e64{0.0, 0.0f, 0, 0};
+    if (act) e = edges[root.edge_base + rank];
+    if (pass) e64 = edges[root.edge_base];
+    const int total = wave_sum_i32(act ? (int)e.n : 0) + (int)e64.n;
+    float pi, pi64;
+    if (temp_zero) {
+        const int best_n = max(wave_max_i32(act ? (int)e.n : -1), pass ? (int)e64.n : -1);
+        const unsigned long long eqm = __ballot(act && (int)e.n == best_n);
+        const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+        pi = lane == amax ? 1.0f : 0.0f;
+        pi64 = amax == 64 ? 1.0f : 0.0f;
+    } else {
+        const float tf = (float)total;
+        pi = act ? (float)e.n / tf : 0.0f;
+        pi64 = pass ? (float)e64.n / tf : 0.0f;
+    }
+    const size_t o = (size_t)g * 65;
+    if (pi_out) { pi_out[o + lane] = pi; if (lane == 0) pi_out[o + 64] = pi64; }
+    if (visits) { visits[o + lane] = act ? (int)e.n : 0; if (lane == 0) visits[o + 64] = (int)e64.n; }
+    if (wsum) { wsum[o + lane] = act ? e.w : 0.0; if (lane == 0) wsum[o + 64] = e64.w; }
+    if (prior) { prior[o + lane] = act ? e.prior : 0.0f; if (lane == 0) prior[o + 64] = e64.prior; }
+}
+
+// ---- compaction of the replay tuples, game-major then ply (parallel_self_play.py:400-405) --------
+__global__ void k_scan_lengths(const int32_t* __restrict__ len, int64_t* __restrict__ off, int n, int64_t* total) {
+    // single block exclusive scan (n <= a few 100k): each thread scans a contiguous chunk
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int per = (n + T - 1) / T;
+    const int lo = t * per, hi = min(lo + per, n);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += len[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int64_t acc = 0;
+        for (int i = 0; i < T; ++i) { const int64_t v = part[i]; part[i] = acc; acc += v; }
+        *total = acc;
+    }
+    __syncthreads();
+    int64_t acc = part[t];
+    for (int i = lo; i < hi; ++i) { off[i] = acc; acc += len[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ hist_bits, const float* __restrict__ hist_pi,
+                                                 const int32_t* __restrict__ len, const int32_t* __restrict__ win,
+                                                 const int64_t* __restrict__ off, int num_games,
+                                                 float* __restrict__ states, float* __restrict__ pis, float* __restrict__ zs) {
+    // one wave per (game, ply) sample; 768 B + 260 B + 4 B written per sample, coalesced rows
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int gid = (int)(w / kMaxPly), ply = (int)(w % kMaxPly);
+    if (gid >= num_games || ply >= len[gid]) return;
+    const size_t h = (size_t)gid * kMaxPly + ply;
+    const int64_t o = off[gid] + ply;
+    const uint64_t sb = hist_bits[h * 3], ob = hist_bits[h * 3 + 1], lg = hist_bits[h * 3 + 2];
+    float* st = states + o * 192;
+    st[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;        // get_tensor_input planes (bitboard.pyx:309-323)
+    st[64 + lane] = (ob >> lane) & 1ULL ? 1.0f : 0.0f;
+    st[128 + lane] = (lg >> lane) & 1ULL ? 1.0f : 0.0f;
+    pis[o * 65 + lane] = hist_pi[h * 65 + lane];
+    if (lane == 0) {
+        pis[o * 65 + 64] = hist_pi[h * 65 + 64];
+        const int player = (ply & 1) ? -1 : 1;           // parallel_self_play.py:385
+        zs[o] = (float)(win[gid] * player);              // parallel_self_play.py:404
+    }
+}
+
+}  // namespace oth
+
+using namespace oth;
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct oth_engine {
+    oth_engine_cfg cfg{};
+    oth_net* net = nullptr;
+    Dev d{};
+    std::vector<void*> allocs;
+    // per-run buffers
+    int32_t hist_games = 0;
+    float *out_states = nullptr, *out_pis = nullptr, *out_zs = nullptr;
+    int64_t out_cap = 0, n_samples = 0;
+    int64_t* d_off = nullptr;
+    int64_t* d_total = nullptr;
+    int32_t n_roots = 0;
+    int32_t run_games = 0;
+    bool lockstep = false;
+    int64_t counters[8] = {0};
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, int>> ev_spans;  // (index of start event, kind 0=net 1=tree)
+    double net_ms = 0, tree_ms = 0;
+    int64_t net_launches = 0, tree_launches = 0;
+    float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
+};
+
+template <typename T>
+static int dev_alloc(oth_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    OTH_HIP(hipMalloc(&q, count * sizeof(T)));
+    OTH_HIP(hipMemset(q, 0, count * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return OTH_OK;
+}
+
+static inline int blocks_for(int n_slots) { return (n_slots + 3) / 4; }
+
+static int span_begin(oth_engine* e, hipStream_t s, int kind) {
+    if (!e->timing) return OTH_OK;
+    if (e->ev_used + 2 > e->ev_pool.size()) {
+        size_t old = e->ev_pool.size(), nw = old ? old * 2 : 4096;
+        e->ev_pool.resize(nw);
+        for (size_t i = old; i < nw; ++i) OTH_HIP(hipEventCreate(&e->ev_pool[i]));
+    }
+    e->ev_spans.push_back({e->ev_used, kind});
+    OTH_HIP(hipEventRecord(e->ev_pool[e->ev_used], s));
+    return OTH_OK;
+}
+static int span_end(oth_engine* e, hipStream_t s) {
+    if (!e->timing) return OTH_OK;
+    OTH_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+    e->ev_used += 2;
+    return OTH_OK;
+}
+static int spans_collect(oth_engine* e) {
+    if (!e->timing) return OTH_OK;
+    for (auto& sp : e->ev_spans) {
+        float ms = 0;
+        OTH_HIP(hipEventElapsedTime(&ms, e->ev_pool[sp.first], e->ev_pool[sp.first + 1]));
+        if (sp.second == 0) { e->net_ms += ms; e->net_launches++; }
+        else { e->tree_ms += ms; e->tree_launches++; }
+    }
+    e->ev_spans.clear();
+    e->ev_used = 0;
+    return OTH_OK;
+}
+static void spans_reset(oth_engine* e) {
+    e->net_ms = e->tree_ms = 0;
+    e->net_launches = e->tree_launches = 0;
+    e->ev_spans.clear();
+    e->ev_used = 0;
+}
+
+static int launch_net(oth_engine* e, hipStream_t s) {
+    OTH_CHECK(e->net, "engine has no network: call oth_engine_set_net (or drive an external evaluator "
+                      "through oth_search_leaves/oth_search_expand)");
+    int r = span_begin(e, s, 0);
+    if (r) return r;
+    r = oth_net_forward_bits(e->net, e->d.ev_self, e->d.ev_opp, e->d.ev_legal, e->d.n_slots, e->d.n_eval, e->d.logp,
+                             e->d.val, s);
+    if (r) return r;
+    e->counters[4]++;
+    return span_end(e, s);
+}
+static int launch_expand(oth_engine* e, const float* pol, const float* val, int is_log, hipStream_t s) {
+    hipLaunchKernelGGL(k_expand, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, pol, val, is_log);
+    OTH_HIP(hipGetLastError());
+    return OTH_OK;
+}
+static int launch_select(oth_engine* e, hipStream_t s) {
+    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_select, dim3(blocks_for(e->d.n_slots)), dim3(256), sizeof(uint32_t) * 4 * e->d.cap_path, s, e->d);
+    OTH_HIP(hipGetLastError());
+    return OTH_OK;
+}
+// roots already queued: evaluate + expand them, then num_simulations x (select, evaluate, expand)
+static int run_search(oth_engine* e, hipStream_t s) {
+    int r;
+    if ((r = launch_net(e, s))) return r;
+    if ((r = span_begin(e, s, 1))) return r;
+    if ((r = launch_expand(e, e->d.logp, e->d.val, 1, s))) return r;
+    if ((r = span_end(e, s))) return r;
+    for (int i = 0; i < e->cfg.num_simulations; ++i) {
+        if ((r = span_begin(e, s, 1))) return r;
+        if ((r = launch_select(e, s))) return r;
+        if ((r = span_end(e, s))) return r;
+        if ((r = launch_net(e, s))) return r;
+        if ((r = span_begin(e, s, 1))) return r;
+        if ((r = launch_expand(e, e->d.logp, e->d.val, 1, s))) return r;
+        if ((r = span_end(e, s))) return r;
+    }
+    return OTH_OK;
+}
+
+static int ensure_history(oth_engine* e, int num_games) {
+    if (num_games <= e->hist_games) return OTH_OK;
+    // (re)allocate per-run history; old buffers stay in allocs until destroy (runs rarely grow)
+    int r;
+    if ((r = dev_alloc(e, &e->d.hist_bits, (size_t)num_games * kMaxPly * 3))) return r;
+    if ((r = dev_alloc(e, &e->d.hist_pi, (size_t)num_games * kMaxPly * 65))) return r;
+    if ((r = dev_alloc(e, &e->d.game_len, (size_t)num_games))) return r;
+    if ((r = dev_alloc(e, &e->d.game_winner, (size_t)num_games))) return r;
+    if ((r = dev_alloc(e, &e->d_off, (size_t)num_games))) return r;
+    e->hist_games = num_games;
+    return OTH_OK;
+}
+
+static int finish_run(oth_engine* e, int num_games, int64_t* n_samples, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, s, e->d.game_len, e->d_off, num_games, e->d_total);
+    OTH_HIP(hipGetLastError());
+    int64_t total = 0;
+    OTH_HIP(hipMemcpyAsync(&total, e->d_total, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    if (total > e->out_cap) {
+        if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
+        const int64_t cap = total + total / 8 + 64;
+        OTH_HIP(hipMalloc(&e->out_states, (size_t)cap * 192 * sizeof(float)));
+        OTH_HIP(hipMalloc(&e->out_pis, (size_t)cap * 65 * sizeof(float)));
+        OTH_HIP(hipMalloc(&e->out_zs, (size_t)cap * sizeof(float)));
+        e->out_cap = cap;
+    }
+    if (total > 0) {
+        const int64_t waves = (int64_t)num_games * kMaxPly;
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, e->d.hist_bits, e->d.hist_pi,
+                           e->d.game_len, e->d.game_winner, e->d_off, num_games, e->out_states, e->out_pis, e->out_zs);
+        OTH_HIP(hipGetLastError());
+    }
+    unsigned long long hc[8];
+    OTH_HIP(hipMemcpyAsync(hc, e->d.counters, sizeof(hc), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 8; ++i)
+        if (i != 4) e->counters[i] = (int64_t)hc[i];
+    e->n_samples = total;
+    e->run_games = num_games;
+    if (n_samples) *n_samples = total;
+    return spans_collect(e);
+}
+
+static int reset_run(oth_engine* e, int num_games, uint64_t seed, hipStream_t s) {
+    int r = ensure_history(e, num_games);
+    if (r) return r;
+    OTH_HIP(hipMemsetAsync(e->d.game_len, 0, sizeof(int32_t) * num_games, s));
+    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8, s));
+    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
+    OTH_HIP(hipMemsetAsync(e->d.n_active, 0, sizeof(int32_t), s));
+    e->d.num_games = num_games;
+    e->d.seed = seed;
+    memset(e->counters, 0, sizeof(e->counters));
+    spans_reset(e);
+    return OTH_OK;
+}
+
+extern "C" {
+
+oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
+    if (!device_ok()) {
+        set_error("oth_engine_create: no gfx950 (MI355X) device available; there is no CPU fallback");
+        return nullptr;
+    }
+    if (!cfg || cfg->max_games < 1 || cfg->num_simulations < 0 || cfg->num_simulations > 60000) {
+        set_error("oth_engine_create: bad configuration");
+        return nullptr;
+    }
+    oth_engine* e = new oth_engine();
+    e->cfg = *cfg;
+    Dev& d = e->d;
+    const int G = cfg->max_games, S = cfg->num_simulations;
+    d.n_slots = G;
+    d.cap_nodes = S + 2;
+    d.cap_edges = (S + 2) * kEdgesPerNode;
+    d.cap_path = S + 2;
+    d.num_sims = S;
+    d.temp_threshold = cfg->temperature_threshold;
+    d.store_late_onehot = cfg->store_late_onehot;
+    d.c_puct = cfg->c_puct;
+    int r = 0;
+    r |= dev_alloc(e, &d.g_self, G); r |= dev_alloc(e, &d.g_opp, G);
+    r |= dev_alloc(e, &d.g_ply, G); r |= dev_alloc(e, &d.g_id, G); r |= dev_alloc(e, &d.g_active, G);
+    r |= dev_alloc(e, &d.nodes, (size_t)G * d.cap_nodes);
+    r |= dev_alloc(e, &d.edges, (size_t)G * d.cap_edges);
+    r |= dev_alloc(e, &d.n_nodes, G); r |= dev_alloc(e, &d.n_edges, G);
+    r |= dev_alloc(e, &d.path, (size_t)G * d.cap_path);
+    r |= dev_alloc(e, &d.path_len, G); r |= dev_alloc(e, &d.pend, G); r |= dev_alloc(e, &d.eval_slot, G);
+    r |= dev_alloc(e, &d.leaf_self, G); r |= dev_alloc(e, &d.leaf_opp, G); r |= dev_alloc(e, &d.leaf_legal, G);
+    // the network kernel reads whole tiles of positions: pad the batch arrays
+    r |= dev_alloc(e, &d.ev_self, (size_t)G + 64); r |= dev_alloc(e, &d.ev_opp, (size_t)G + 64);
+    r |= dev_alloc(e, &d.ev_legal, (size_t)G + 64);
+    r |= dev_alloc(e, &d.n_eval, 4);
+    r |= dev_alloc(e, &d.logp, ((size_t)G + 64) * 65); r |= dev_alloc(e, &d.val, (size_t)G + 64);
+    r |= dev_alloc(e, &d.next_game, 4); r |= dev_alloc(e, &d.n_active, 4);
+    r |= dev_alloc(e, &d.counters, 8);
+    r |= dev_alloc(e, &e->d_total, 2);
+    double* st = nullptr;
+    r |= dev_alloc(e, &st, (size_t)S + 4);
+    if (r) { oth_engine_destroy(e); return nullptr; }
+    std::vector<double> tab(S + 4);
+    for (int i = 0; i < S + 4; ++i) tab[i] = sqrt((double)i);  // correctly rounded, == np.sqrt(int)
+    if (hipMemcpy(st, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("oth_engine_create: upload failed");
+        oth_engine_destroy(e);
+        return nullptr;
+    }
+    d.sqrt_tab = st;
+    if (hipHostMalloc((void**)&e->h_stage, sizeof(float) * (size_t)G * 66) != hipSuccess) e->h_stage = nullptr;
+    return e;
+}
+
+void oth_engine_destroy(oth_engine* e) {
+    if (!e) return;
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    delete e;
+}
+
+int oth_engine_set_net(oth_engine* e, oth_net* net) {
+    OTH_CHECK(e, "oth_engine_set_net: null engine");
+    e->net = net;
+    return OTH_OK;
+}
+
+// ---- step-wise search ----------------------------------------------------------------------------
+int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int32_t n, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && sb && ob && n >= 1 && n <= e->d.n_slots, "oth_search_begin: need 1 <= n <= max_games roots");
+    hipStream_t s = as_stream(stream);
+    // the roots are uploaded straight into the game-position arrays; k_search_begin reads them there
+    OTH_HIP(hipMemcpyAsync(e->d.g_self, sb, sizeof(uint64_t) * n, hipMemcpyDefault, s));
+    OTH_HIP(hipMemcpyAsync(e->d.g_opp, ob, sizeof(uint64_t) * n, hipMemcpyDefault, s));
+    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
+    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8, s));
+    memset(e->counters, 0, sizeof(e->counters));
+    spans_reset(e);
+    hipLaunchKernelGGL(k_search_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.g_self, e->d.g_opp, n);
+    OTH_HIP(hipGetLastError());
+    e->n_roots = n;
+    return OTH_OK;
+}
+
+int oth_search_select(oth_engine* e, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->n_roots > 0, "oth_search_select: call oth_search_begin first");
+    return launch_select(e, as_stream(stream));
+}
+
+int oth_search_leaves(oth_engine* e, int32_t* count, uint64_t* sb, uint64_t* ob, uint64_t* lg, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && count, "oth_search_leaves: null argument");
+    hipStream_t s = as_stream(stream);
+    int32_t n = 0;
+    OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    *count = n;
+    if (n > 0) {
+        if (sb) OTH_HIP(hipMemcpyAsync(sb, e->d.ev_self, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, s));
+        if (ob) OTH_HIP(hipMemcpyAsync(ob, e->d.ev_opp, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, s));
+        if (lg) OTH_HIP(hipMemcpyAsync(lg, e->d.ev_legal, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, s));
+        OTH_HIP(hipStreamSynchronize(s));
+    }
+    return OTH_OK;
+}
+
+int oth_search_expand(oth_engine* e, const float* policy, const float* value, int32_t is_log, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && policy && value, "oth_search_expand: null argument");
+    hipStream_t s = as_stream(stream);
+    int32_t n = 0;
+    OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    if (n > 0) {  // caller memory may be host or device: stage into the engine's own arrays
+        OTH_HIP(hipMemcpyAsync(e->d.logp, policy, sizeof(float) * 65 * n, hipMemcpyDefault, s));
+        OTH_HIP(hipMemcpyAsync(e->d.val, value, sizeof(float) * n, hipMemcpyDefault, s));
+    }
+    return launch_expand(e, e->d.logp, e->d.val, is_log ? 1 : 0, s);
+}
+
+int oth_search_run(oth_engine* e, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->n_roots > 0, "oth_search_run: call oth_search_begin first");
+    return run_search(e, as_stream(stream));
+}
+
+int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* visits, double* wsum, float* prior,
+                       void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->n_roots > 0, "oth_search_results: no search in progress");
+    OTH_CHECK(temperature == 0.0 || temperature == 1.0, "oth_search_results: temperature must be 0 or 1");
+    hipStream_t s = as_stream(stream);
+    const int n = e->n_roots;
+    float *dpi = nullptr, *dpr = nullptr;
+    int32_t* dv = nullptr;
+    double* dw = nullptr;
+    OTH_HIP(hipMalloc(&dpi, sizeof(float) * 65 * n));
+    OTH_HIP(hipMalloc(&dpr, sizeof(float) * 65 * n));
+    OTH_HIP(hipMalloc(&dv, sizeof(int32_t) * 65 * n));
+    OTH_HIP(hipMalloc(&dw, sizeof(double) * 65 * n));
+    hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, temperature == 0.0 ? 1 : 0, dpi, dv, dw, dpr);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess && pi) err = hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess && visits) err = hipMemcpyAsync(visits, dv, sizeof(int32_t) * 65 * n, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess && wsum) err = hipMemcpyAsync(wsum, dw, sizeof(double) * 65 * n, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess && prior) err = hipMemcpyAsync(prior, dpr, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(dpi); (void)hipFree(dpr); (void)hipFree(dv); (void)hipFree(dw);
+    OTH_HIP(err);
+    unsigned long long hc[8];
+    OTH_HIP(hipMemcpy(hc, e->d.counters, sizeof(hc), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i)
+        if (i != 4) e->counters[i] = (int64_t)hc[i];
+    return spans_collect(e);
+}
+
+// ---- self-play -----------------------------------------------------------------------------------
+int oth_selfplay_run(oth_engine* e, int32_t num_games, uint64_t seed, int32_t add_noise, int64_t* n_samples,
+                     void* stream) {
+    OTH_NEED_DEVICE();
+    (void)add_noise;  // no observable effect on this search: see the header comment
+    OTH_CHECK(e && num_games >= 1, "oth_selfplay_run: bad arguments");
+    OTH_CHECK(e->net, "oth_selfplay_run: no network set");
+    hipStream_t s = as_stream(stream);
+    int r = reset_run(e, num_games, seed, s);
+    if (r) return r;
+    const int G = e->d.n_slots;
+    const int n_start = num_games < G ? num_games : G;
+    OTH_HIP(hipMemcpyAsync(e->d.next_game, &n_start, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_games_begin, dim3(blocks_for(G)), dim3(256), 0, s, e->d, n_start);
+    OTH_HIP(hipGetLastError());
+    e->lockstep = false;
+    e->n_roots = 0;
+    for (int64_t step = 0;; ++step) {
+        if ((r = run_search(e, s))) return r;
+        if ((r = span_begin(e, s, 1))) return r;
+        OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_ply, dim3(blocks_for(G)), dim3(256), 0, s, e->d, (const int32_t*)nullptr, 1);
+        OTH_HIP(hipGetLastError());
+        if ((r = span_end(e, s))) return r;
+        int32_t active = 0;
+        OTH_HIP(hipMemcpyAsync(&active, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        OTH_HIP(hipStreamSynchronize(s));
+        if (active <= 0) break;
+        if (step > (int64_t)kMaxPly * ((num_games + G - 1) / G + 1)) {
+            set_error("oth_selfplay_run: games did not finish (internal error)");
+            return OTH_E_STATE;
+        }
+    }
+    return finish_run(e, num_games, n_samples, s);
+}
+
+int oth_selfplay_begin(oth_engine* e, int32_t n, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && n >= 1 && n <= e->d.n_slots, "oth_selfplay_begin: need 1 <= n <= max_games");
+    hipStream_t s = as_stream(stream);
+    int r = reset_run(e, n, 0, s);
+    if (r) return r;
+    OTH_HIP(hipMemcpyAsync(e->d.next_game, &n, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_games_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, n);
+    OTH_HIP(hipGetLastError());
+    e->lockstep = true;
+    e->n_roots = n;
+    return OTH_OK;
+}
+
+int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->lockstep, "oth_selfplay_search: call oth_selfplay_begin first");
+    hipStream_t s = as_stream(stream);
+    int r = run_search(e, s);
+    if (r) return r;
+    const int n = e->n_roots;
+    if (active) OTH_HIP(hipMemcpyAsync(active, e->d.g_active, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    if (pi) {
+        float* dpi = nullptr;
+        OTH_HIP(hipMalloc(&dpi, sizeof(float) * 65 * n));
+        OTH_HIP(hipMemsetAsync(dpi, 0, sizeof(float) * 65 * n, s));
+        // finished games keep a stale tree: their rows are garbage by contract (active[i] == 0)
+        hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, 0, dpi, (int32_t*)nullptr,
+                           (double*)nullptr, (float*)nullptr);
+        hipError_t err = hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
+        if (err == hipSuccess) err = hipStreamSynchronize(s);
+        (void)hipFree(dpi);
+        OTH_HIP(err);
+    }
+    OTH_HIP(hipStreamSynchronize(s));
+    return OTH_OK;
+}
+
+int oth_selfplay_apply(oth_engine* e, const int32_t* actions, int32_t* n_unfinished, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->lockstep && actions, "oth_selfplay_apply: bad state or arguments");
+    hipStream_t s = as_stream(stream);
+    int32_t* dact = nullptr;
+    OTH_HIP(hipMalloc(&dact, sizeof(int32_t) * e->d.n_slots));
+    OTH_HIP(hipMemsetAsync(dact, 0, sizeof(int32_t) * e->d.n_slots, s));
+    OTH_HIP(hipMemcpyAsync(dact, actions, sizeof(int32_t) * e->n_roots, hipMemcpyDefault, s));
+    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_ply, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, (const int32_t*)dact, 0);
+    hipError_t err = hipGetLastError();
+    int32_t act = 0;
+    if (err == hipSuccess) err = hipMemcpyAsync(&act, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(dact);
+    OTH_HIP(err);
+    if (n_unfinished) *n_unfinished = act;
+    return OTH_OK;
+}
+
+int oth_selfplay_end(oth_engine* e, int64_t* n_samples, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->lockstep, "oth_selfplay_end: no lock-step run in progress");
+    e->lockstep = false;
+    const int n = e->n_roots;
+    e->n_roots = 0;
+    return finish_run(e, n, n_samples, as_stream(stream));
+}
+
+int oth_selfplay_fetch(oth_engine* e, float* states, float* pis, float* zs, int32_t* game_len, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e, "oth_selfplay_fetch: null engine");
+    hipStream_t s = as_stream(stream);
+    const int64_t n = e->n_samples;
+    if (n > 0) {
+        if (states) OTH_HIP(hipMemcpyAsync(states, e->out_states, (size_t)n * 192 * sizeof(float), hipMemcpyDefault, s));
+        if (pis) OTH_HIP(hipMemcpyAsync(pis, e->out_pis, (size_t)n * 65 * sizeof(float), hipMemcpyDefault, s));
+        if (zs) OTH_HIP(hipMemcpyAsync(zs, e->out_zs, (size_t)n * sizeof(float), hipMemcpyDefault, s));
+    }
+    if (game_len && e->run_games > 0)
+        OTH_HIP(hipMemcpyAsync(game_len, e->d.game_len, sizeof(int32_t) * e->run_games, hipMemcpyDefault, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    return OTH_OK;
+}
+
+int oth_selfplay_device_ptrs(oth_engine* e, float** states, float** pis, float** zs, int64_t* n_samples) {
+    OTH_CHECK(e, "oth_selfplay_device_ptrs: null engine");
+    if (states) *states = e->out_states;
+    if (pis) *pis = e->out_pis;
+    if (zs) *zs = e->out_zs;
+    if (n_samples) *n_samples = e->n_samples;
+    return OTH_OK;
+}
+
+int oth_engine_counters(oth_engine* e, int64_t out[8]) {
+    OTH_CHECK(e && out, "oth_engine_counters: null argument");
+    for (int i = 0; i < 8; ++i) out[i] = e->counters[i];
+    return OTH_OK;
+}
+
+int oth_engine_set_timing(oth_engine* e, int32_t enable) {
+    OTH_CHECK(e, "oth_engine_set_timing: null engine");
+    e->timing = enable != 0;
+    return OTH_OK;
+}
+
+int oth_engine_kernel_time(oth_engine* e, double* net_ms, int64_t* net_launches, double* tree_ms, int64_t* tree_launches) {
+    OTH_CHECK(e, "oth_engine_kernel_time: null engine");
+    if (net_ms) *net_ms = e->net_ms;
+    if (net_launches) *net_launches = e->net_launches;
+    if (tree_ms) *tree_ms = e->tree_ms;
+    if (tree_launches) *tree_launches = e->tree_launches;
+    return OTH_OK;
+}
+
+}  // extern "C"

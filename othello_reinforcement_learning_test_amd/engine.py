@@ -1,0 +1,251 @@
+"""Python handles over sections 3 and 4 of the C ABI: the HIP evaluator and the search/self-play
+engine.  Used by mcts.py, self_play.py and parallel_self_play.py (the mirrors of the reference
+classes); nothing here computes anything on the host.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def default_precision(num_filters):
+    """128-filter networks run on the MFMA trunk with the fp32-equivalent fp16x3 split; other
+    widths use the generic fp32 kernel."""
+    return "f16x3" if num_filters == 128 else "f32"
+
+
+class HipResNetEvaluator:
+    """OthelloResNet forward (reference net.py:182-205, eval mode) on the GPU.
+
+    ``model`` is any module with the reference's state_dict layout (the reference's own
+    OthelloResNet or net.OthelloResNet).  The trainer keeps updating that module between
+    ``execute_episodes`` calls (SURVEY 8(b) threading note), so ``refresh()`` re-reads the weights
+    whenever a parameter/buffer version counter has moved.
+    """
+
+    def __init__(self, model, precision=None):
+        _lib.require_device()
+        self.model = model
+        self.num_blocks = int(getattr(model, "num_blocks", len(model.res_blocks)))
+        self.num_filters = int(getattr(model, "num_filters", model.conv_block.conv.out_channels))
+        board_size = int(getattr(model, "board_size", 8))
+        self.precision = precision or default_precision(self.num_filters)
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
+        self._h = _lib.load().oth_net_create(self.num_blocks, self.num_filters, board_size)
+        if not self._h:
+            raise _lib.OthelloHipError("oth_net_create: " + _lib.last_error())
+        self._version = None
+        self.refresh()
+
+    def _model_version(self):
+        v = 0
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            v += int(t._version) + 1
+        return v
+
+    def refresh(self, force=False):
+        """Re-upload (fold + repack) the weights if the model changed since the last call."""
+        ver = self._model_version()
+        if force or ver != self._version:
+            blob = _lib.state_dict_blob(self.model.state_dict())
+            _lib.call("oth_net_load_state", self._h, _lib.np_ptr(blob, C.c_float), blob.size,
+                      _lib.PRECISIONS[self.precision])
+            self._version = ver
+
+    @property
+    def handle(self):
+        return self._h
+
+    def forward_planes(self, x):
+        """x: CUDA float32 (N,3,8,8) of 0/1 planes -> (log-probs (N,65), value (N,1)) CUDA tensors."""
+        import torch
+        x = x.contiguous()
+        n = x.shape[0]
+        logp = torch.empty((n, 65), dtype=torch.float32, device=x.device)
+        v = torch.empty((n,), dtype=torch.float32, device=x.device)
+        _lib.call("oth_net_forward_planes", self._h, x.data_ptr(), n, logp.data_ptr(), v.data_ptr(),
+                  _lib.current_stream())
+        return logp, v.view(n, 1)
+
+    def forward_bits(self, self_b, opp_b, legal):
+        """Packed-bitboard input (CUDA int64 tensors) -> (log-probs, value)."""
+        import torch
+        n = self_b.numel()
+        logp = torch.empty((n, 65), dtype=torch.float32, device=self_b.device)
+        v = torch.empty((n,), dtype=torch.float32, device=self_b.device)
+        _lib.call("oth_net_forward_bits", self._h, self_b.data_ptr(), opp_b.data_ptr(), legal.data_ptr(),
+                  n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
+        return logp, v.view(n, 1)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().oth_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class SearchEngine:
+    """Handle over oth_engine: G concurrent game slots, one wavefront per game on the device."""
+
+    def __init__(self, max_games, num_simulations, temperature_threshold=15, c_puct=1.0,
+                 dirichlet_alpha=0.3, dirichlet_epsilon=0.25, store_late_onehot=False, evaluator=None):
+        _lib.require_device()
+        self.max_games = int(max_games)
+        self.num_simulations = int(num_simulations)
+        cfg = _lib.EngineCfg(self.max_games, self.num_simulations, int(temperature_threshold),
+                             float(c_puct), float(dirichlet_alpha), float(dirichlet_epsilon),
+                             1 if store_late_onehot else 0, 0)
+        self._h = _lib.load().oth_engine_create(C.byref(cfg))
+        if not self._h:
+            raise _lib.OthelloHipError("oth_engine_create: " + _lib.last_error())
+        self.evaluator = None
+        if evaluator is not None:
+            self.set_evaluator(evaluator)
+
+    def set_evaluator(self, evaluator):
+        self.evaluator = evaluator
+        _lib.call("oth_engine_set_net", self._h, evaluator.handle)
+
+    # ---- step-wise search ------------------------------------------------------------------
+    def search_begin(self, self_b, opp_b):
+        s = np.ascontiguousarray(self_b, dtype=np.uint64)
+        o = np.ascontiguousarray(opp_b, dtype=np.uint64)
+        self._n = len(s)
+        _lib.call("oth_search_begin", self._h, _lib.np_ptr(s, C.c_uint64), _lib.np_ptr(o, C.c_uint64),
+                  self._n, _lib.current_stream())
+
+    def search_select(self):
+        _lib.call("oth_search_select", self._h, _lib.current_stream())
+
+    def search_leaves(self):
+        cnt = C.c_int32(0)
+        s = np.zeros(self.max_games, dtype=np.uint64)
+        o = np.zeros(self.max_games, dtype=np.uint64)
+        lg = np.zeros(self.max_games, dtype=np.uint64)
+        _lib.call("oth_search_leaves", self._h, C.byref(cnt), _lib.np_ptr(s, C.c_uint64),
+                  _lib.np_ptr(o, C.c_uint64), _lib.np_ptr(lg, C.c_uint64), _lib.current_stream())
+        n = cnt.value
+        return s[:n], o[:n], lg[:n]
+
+    def search_expand(self, policy, value, is_log=False):
+        p = np.ascontiguousarray(policy, dtype=np.float32)
+        v = np.ascontiguousarray(value, dtype=np.float32)
+        _lib.call("oth_search_expand", self._h, p.ctypes.data, v.ctypes.data, 1 if is_log else 0,
+                  _lib.current_stream())
+
+    def search_run(self):
+        _lib.call("oth_search_run", self._h, _lib.current_stream())
+
+    def search_results(self, temperature=1.0):
+        n = self._n
+        pi = np.zeros((n, 65), dtype=np.float32)
+        visits = np.zeros((n, 65), dtype=np.int32)
+        wsum = np.zeros((n, 65), dtype=np.float64)
+        prior = np.zeros((n, 65), dtype=np.float32)
+        _lib.call("oth_search_results", self._h, float(temperature), _lib.np_ptr(pi, C.c_float),
+                  _lib.np_ptr(visits, C.c_int32), _lib.np_ptr(wsum, C.c_double),
+                  _lib.np_ptr(prior, C.c_float), _lib.current_stream())
+        return pi, visits, wsum, prior
+
+    def search_with(self, self_b, opp_b, eval_fn, temperature=1.0):
+        """Whole search with an external evaluator: eval_fn(self u64[m], opp u64[m], legal u64[m])
+        -> (probs f32[m,65], values f32[m]).  Mirrors BatchMCTS.search_batch."""
+        self.search_begin(self_b, opp_b)
+        s, o, lg = self.search_leaves()
+        p, v = eval_fn(s, o, lg)
+        self.search_expand(p, v, is_log=False)
+        for _ in range(self.num_simulations):
+            self.search_select()
+            s, o, lg = self.search_leaves()
+            if len(s):
+                p, v = eval_fn(s, o, lg)
+            else:
+                p, v = np.zeros((1, 65), np.float32), np.zeros(1, np.float32)
+            self.search_expand(p, v, is_log=False)
+        return self.search_results(temperature)
+
+    # ---- self-play -------------------------------------------------------------------------
+    def selfplay_run(self, num_games, seed, add_noise=True):
+        n = C.c_int64(0)
+        _lib.call("oth_selfplay_run", self._h, int(num_games), C.c_uint64(int(seed) & (2**64 - 1)),
+                  1 if add_noise else 0, C.byref(n), _lib.current_stream())
+        self._run_games = int(num_games)
+        return n.value
+
+    def selfplay_begin(self, n):
+        self._n = int(n)
+        self._run_games = int(n)
+        _lib.call("oth_selfplay_begin", self._h, self._n, _lib.current_stream())
+
+    def selfplay_search(self):
+        pi = np.zeros((self._n, 65), dtype=np.float32)
+        active = np.zeros(self._n, dtype=np.int32)
+        _lib.call("oth_selfplay_search", self._h, _lib.np_ptr(pi, C.c_float),
+                  _lib.np_ptr(active, C.c_int32), _lib.current_stream())
+        return pi, active
+
+    def selfplay_apply(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        left = C.c_int32(0)
+        _lib.call("oth_selfplay_apply", self._h, _lib.np_ptr(a, C.c_int32), C.byref(left),
+                  _lib.current_stream())
+        return left.value
+
+    def selfplay_end(self):
+        n = C.c_int64(0)
+        _lib.call("oth_selfplay_end", self._h, C.byref(n), _lib.current_stream())
+        return n.value
+
+    def selfplay_fetch(self, n_samples):
+        """-> host numpy arrays (states (n,3,8,8), pis (n,65), zs (n,), game_len (games,))"""
+        st = np.empty((n_samples, 3, 8, 8), dtype=np.float32)
+        pi = np.empty((n_samples, 65), dtype=np.float32)
+        z = np.empty((n_samples,), dtype=np.float32)
+        gl = np.zeros((self._run_games,), dtype=np.int32)
+        _lib.call("oth_selfplay_fetch", self._h, st.ctypes.data, pi.ctypes.data, z.ctypes.data,
+                  gl.ctypes.data, _lib.current_stream())
+        return st, pi, z, gl
+
+    def selfplay_device_tensors(self):
+        """Zero-copy CUDA views of the compacted replay tuples of the last run (valid until the
+        next run): for on-device consumers such as the RCCL all-gather."""
+        import torch
+        ps, pp, pz, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        _lib.call("oth_selfplay_device_ptrs", self._h, C.byref(ps), C.byref(pp), C.byref(pz), C.byref(n))
+        n = n.value
+
+        def view(ptr, shape):
+            if n == 0:
+                return torch.empty(shape, dtype=torch.float32, device="cuda")
+            numel = int(np.prod(shape))
+            iface = {"shape": (numel,), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+            holder = type("_DevMem", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device="cuda").view(*shape)
+        return view(ps, (n, 3, 8, 8)), view(pp, (n, 65)), view(pz, (n,))
+
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        _lib.call("oth_engine_counters", self._h, out)
+        keys = ("evals", "simulations", "plies", "games", "net_batches", "terminal_sims")
+        return dict(zip(keys, list(out)[:6]))
+
+    def set_timing(self, enable=True):
+        _lib.call("oth_engine_set_timing", self._h, 1 if enable else 0)
+
+    def kernel_time(self):
+        nm, tm = C.c_double(0), C.c_double(0)
+        nl, tl = C.c_int64(0), C.c_int64(0)
+        _lib.call("oth_engine_kernel_time", self._h, C.byref(nm), C.byref(nl), C.byref(tm), C.byref(tl))
+        return {"net_ms": nm.value, "net_launches": nl.value, "tree_ms": tm.value, "tree_launches": tl.value}
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().oth_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

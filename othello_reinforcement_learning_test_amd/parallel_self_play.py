@@ -1,0 +1,175 @@
+"""BatchMCTS / ParallelSelfPlayWorker / create_parallel_self_play_worker -- mirrors of
+/root/reference/src/train/parallel_self_play.py:31-434, backed by the HIP engine.
+
+The reference's schedule (N lock-step games, one leaf per game per simulation step, one batched
+network call per step) is exactly the device schedule: one wavefront per game, one network launch
+per simulation step over the dense leaf batch.
+
+Parallel-worker semantics kept: the search always runs at temperature 1 and the
+stored pi is always the visit distribution; argmax only picks the move after the threshold.
+"""
+import os
+import time
+
+import numpy as np
+
+from .engine import HipResNetEvaluator, SearchEngine
+from .self_play import tuples_from_arrays
+
+
+class BatchMCTS:
+    """search_batch(boards, num_simulations, temperature, add_dirichlet_noise) -> [(pi, value)]
+    (parallel_self_play.py:80-170)."""
+
+    def __init__(self, model, device=None, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
+                 precision=None, evaluator=None):
+        self.model = model
+        self.device = device
+        self.c_puct = c_puct
+        self.dirichlet_alpha = dirichlet_alpha
+        self.dirichlet_epsilon = dirichlet_epsilon
+        self.evaluator = evaluator or HipResNetEvaluator(model, precision=precision)
+        self._engines = {}
+
+    def _engine(self, n_boards, num_simulations):
+        cap = 1
+        while cap < n_boards:
+            cap *= 2
+        key = (cap, int(num_simulations))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = SearchEngine(cap, num_simulations, c_puct=self.c_puct,
+                               dirichlet_alpha=self.dirichlet_alpha,
+                               dirichlet_epsilon=self.dirichlet_epsilon, evaluator=self.evaluator)
+            self._engines[key] = eng
+        return eng
+
+    def search_batch(self, boards, num_simulations, temperature=1.0, add_dirichlet_noise=False):
+        n = len(boards)
+        if n == 0:
+            return []
+        if temperature not in (0, 0.0, 1, 1.0):
+            raise ValueError("temperature must be 0 or 1")
+        self.evaluator.refresh()
+        if add_dirichlet_noise:  # :111-118: one draw per board, in board order
+            for b in boards:
+                np.random.dirichlet([self.dirichlet_alpha] * len(b.get_legal_moves()))
+        eng = self._engine(n, num_simulations)
+        eng.search_begin([b.self_board for b in boards], [b.opp_board for b in boards])
+        eng.search_run()
+        pi, _, _, _ = eng.search_results(float(temperature))
+        return [(pi[i].copy(), 0.0) for i in range(n)]  # root value is always 0.0
+
+
+class ParallelSelfPlayWorker:
+    def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
+                 num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
+                 rng_mode=None, precision=None, verbose=True):
+        self.board_class = board_class
+        self.num_simulations = num_simulations
+        self.temperature_threshold = temperature_threshold
+        self.num_parallel_games = num_parallel_games
+        self.rng_mode = rng_mode or os.environ.get("OTHELLO_AMD_RNG", "device")
+        if self.rng_mode not in ("device", "numpy"):
+            raise ValueError("rng_mode must be 'device' or 'numpy'")
+        self.verbose = verbose
+        self.batch_mcts = BatchMCTS(model, device, c_puct, dirichlet_alpha, dirichlet_epsilon,
+                                    precision=precision)
+        self.engine = SearchEngine(num_parallel_games, num_simulations,
+                                   temperature_threshold=temperature_threshold, c_puct=c_puct,
+                                   dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
+                                   store_late_onehot=False, evaluator=self.batch_mcts.evaluator)
+        self.last_stats = {}
+
+    # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------
+    def _run_device(self, num_episodes, add_dirichlet_noise):
+        seed = int(np.random.randint(0, 2**62))
+        n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
+        return self.engine.selfplay_fetch(n)[:3]
+
+    # ---- numpy RNG: the reference's lock-step batches, draws in the reference's order --------
+    def _execute_batch_numpy(self, batch_size, add_dirichlet_noise):
+        """parallel_self_play.py:324-407 with the search, recording and moves on the device; the
+        host only draws the random numbers (it mirrors the boards to know the legal-move counts)."""
+        eng = self.engine
+        boards = [self.board_class() for _ in range(batch_size)]
+        for b in boards:
+            b.reset()
+        finished = [False] * batch_size
+        ply = [0] * batch_size
+        eng.selfplay_begin(batch_size)
+        alpha = self.batch_mcts.dirichlet_alpha
+        while not all(finished):
+            active = [i for i in range(batch_size) if not finished[i]]
+            if add_dirichlet_noise:  # drawn inside search_batch, board by board (:111-118)
+                for i in active:
+                    np.random.dirichlet([alpha] * len(boards[i].get_legal_moves()))
+            pi, _ = eng.selfplay_search()
+            actions = np.zeros(batch_size, dtype=np.int32)
+            for i in active:  # :375-397
+                if ply[i] < self.temperature_threshold:
+                    a = int(np.random.choice(65, p=pi[i]))
+                else:
+                    a = int(np.argmax(pi[i]))
+                actions[i] = a
+                boards[i].make_move(a)
+                ply[i] += 1
+                if boards[i].is_terminal():
+                    finished[i] = True
+            eng.selfplay_apply(actions)
+        n = eng.selfplay_end()
+        return eng.selfplay_fetch(n)[:3]
+
+    def execute_episodes(self, num_episodes, add_dirichlet_noise=True):
+        """-> [(state, pi, z), ...] game-major (parallel_self_play.py:282-322)."""
+        if num_episodes <= 0:
+            return []
+        self.batch_mcts.evaluator.refresh()
+        t0 = time.time()
+        if self.rng_mode == "device":
+            states, pis, zs = self._run_device(num_episodes, add_dirichlet_noise)
+            data = tuples_from_arrays(states, pis, zs)
+        else:
+            data = []
+            done = 0
+            while done < num_episodes:  # :300-316
+                bs = min(self.num_parallel_games, num_episodes - done)
+                states, pis, zs = self._execute_batch_numpy(bs, add_dirichlet_noise)
+                data.extend(tuples_from_arrays(states, pis, zs))
+                done += bs
+        dt = time.time() - t0
+        self.last_stats = {"games": num_episodes, "samples": len(data), "seconds": dt,
+                           "games_per_s": num_episodes / dt if dt > 0 else float("inf"),
+                           **self.engine.counters()}
+        if self.verbose:
+            print("  Self-Play: %d/%d games | %s samples | %.1fs (%.2f games/s)" %
+                  (num_episodes, num_episodes, format(len(data), ","), dt, self.last_stats["games_per_s"]))
+        return data
+
+    def execute_episodes_arrays(self, num_episodes, add_dirichlet_noise=True, seed=None):
+        """Array form for callers that keep replay data on the device side: (states, pis, zs)."""
+        self.batch_mcts.evaluator.refresh()
+        if seed is None:
+            seed = int(np.random.randint(0, 2**62))
+        n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
+        return self.engine.selfplay_fetch(n)[:3]
+
+
+def create_parallel_self_play_worker(config, model, device=None, **kwargs):
+    """Build from a reference YAML config dict (parallel_self_play.py:410-434); same keys, same
+    defaults."""
+    from .bitboard import OthelloBitboard
+    mcts = config.get("mcts", {})
+    sp = config.get("self_play", {})
+    return ParallelSelfPlayWorker(
+        board_class=OthelloBitboard,
+        model=model,
+        device=device,
+        num_simulations=mcts.get("num_simulations", 25),
+        temperature_threshold=sp.get("temperature_threshold", 15),
+        num_parallel_games=sp.get("num_parallel_games", 8),
+        c_puct=mcts.get("c_puct", 1.0),
+        dirichlet_alpha=mcts.get("dirichlet_alpha", 0.3),
+        dirichlet_epsilon=mcts.get("dirichlet_epsilon", 0.25),
+        **kwargs,
+    )

@@ -1,0 +1,120 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol the
+header declares; the host-side single-board API (compiled from the same othello_rules.h as the
+device kernels) matches the golden vectors and the oracle; device entry points fail loudly without a
+GPU (no fallback).  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from othello_reinforcement_learning_test_amd import OthelloBitboard, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "othello_mi355x.h")).read()
+    names = sorted(set(re.findall(r"\b(oth_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 40
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    assert set(names) == set(_lib._SIGS), "ctypes table and header disagree"
+
+
+def test_host_rules_vs_golden(golden):
+    g = golden("g1_rules.npz")
+    L = _lib.load()
+    for arr, lcol, fcol, mcol in ((g["game_pos"], 2, 3, g["game_meta"][:, 0]),
+                                  (g["crafted_pos"], 2, 3, g["crafted_meta"][:, 0])):
+        for row, mv in zip(arr, mcol):
+            s, o = int(row[0]), int(row[1])
+            assert L.oth_legal_moves(s, o) == int(row[lcol])
+            if mv < 64:
+                assert L.oth_flip_bits(int(mv), s, o) == int(row[fcol])
+    n, la, fa = (int(x) for x in g["checksum"])
+    assert ol.rules_checksum(n) == (la, fa)
+
+
+def test_board_object_follows_reference_games(golden):
+    g = golden("g1_rules.npz")
+    pos, meta, gid = g["game_pos"], g["game_meta"], g["game_id"]
+    b = None
+    for i in range(len(pos)):
+        if i == 0 or gid[i] != gid[i - 1]:
+            b = OthelloBitboard()
+        assert (b.self_board, b.opp_board, b.move_count) == (int(pos[i, 0]), int(pos[i, 1]), int(meta[i, 3]))
+        assert b.get_legal_moves_bits() == int(pos[i, 2])
+        assert b.is_terminal() == bool(meta[i, 1])
+        assert b.get_winner() == int(np.int8(meta[i, 2]))
+        if not meta[i, 1]:
+            lm = b.get_legal_moves()
+            assert int(meta[i, 0]) in lm
+            assert b.make_move(int(meta[i, 0])) is True
+            assert b.passed == (meta[i, 0] == 64)
+
+
+def test_board_invalid_moves_and_fields(golden):
+    g = golden("g1_rules.npz")
+    for (mv, ok, _s, _o, mc, passed), (s, o) in zip(g["invalid"], g["invalid_u64"]):
+        b = OthelloBitboard()
+        assert b.make_move(int(mv)) == bool(ok)
+        assert (b.self_board, b.opp_board, b.move_count, int(b.passed)) == (int(s), int(o), mc, passed)
+    b = OthelloBitboard()
+    b.self_board, b.opp_board = 1 << 9, 1 << 8       # fields are writable (bitboard.pxd:25-28)
+    assert (b.get_legal_moves_bits() >> 7) & 1        # H1 legal by wrap
+    c = b.copy()
+    c.make_move(7)
+    assert b.self_board == 1 << 9 and c.move_count == 1  # copy independence (test_bitboard.py:179-192)
+    assert b.get_stone_counts() == (1, 1)
+
+
+def test_tensor_and_symmetries(golden):
+    g = golden("g2_tensor.npz")
+    rng = np.random.Generator(np.random.PCG64(3))
+    for (s, o), t in zip(g["pos"], g["tensor"]):
+        b = OthelloBitboard()
+        b.self_board, b.opp_board = int(s), int(o)
+        x = b.get_tensor_input()
+        assert x.dtype == np.float32 and x.shape == (3, 8, 8) and x.flags["C_CONTIGUOUS"]
+        assert np.array_equal(x, t.astype(np.float32))
+    for (s, o) in g["pos"][:40]:
+        b = OthelloBitboard()
+        b.self_board, b.opp_board = int(s), int(o)
+        pi = rng.random(65).astype(np.float32)
+        st, ps = ol.symmetries(ol.board(s, o), pi)
+        got = b.get_symmetries(pi)
+        assert len(got) == 8
+        for k in range(8):
+            assert got[k][0].shape == (3, 8, 8) and got[k][1].shape == (65,)
+            assert np.array_equal(got[k][0], st[k]) and np.array_equal(got[k][1], ps[k])
+
+
+def test_repr_and_known_answers():
+    b = OthelloBitboard()
+    assert b.get_legal_moves() == [19, 26, 37, 44]            # reference tests/test_bitboard.py:29-37
+    assert b.make_move(19) and b.get_stone_counts() == (1, 4)  # :60-71
+    assert not b.make_move(19)                                 # :73-87
+    r = b.to_string().split("\n")
+    assert r[0] == "  A B C D E F G H" and len(r) == 9
+
+
+def test_no_gpu_means_loud_failure():
+    """Without an MI355X the compute classes must raise, never fall back to the CPU."""
+    if _lib.device_available():
+        pytest.skip("a GPU is present")
+    from othello_reinforcement_learning_test_amd import (MCTS, OthelloHipError, OthelloResNet,
+                                                         ParallelSelfPlayWorker, SearchEngine)
+    with pytest.raises(OthelloHipError):
+        SearchEngine(4, 5)
+    net = OthelloResNet(2, 16)
+    with pytest.raises(OthelloHipError):
+        MCTS(net)
+    with pytest.raises(OthelloHipError):
+        ParallelSelfPlayWorker(OthelloBitboard, net, num_parallel_games=2, num_simulations=2)
+    out = np.zeros(4, dtype=np.uint64)
+    assert _lib.load().oth_legal_moves_batch(out.ctypes.data, out.ctypes.data, out.ctypes.data, 4, None) == -1
+    assert "no gfx950" in _lib.last_error()
