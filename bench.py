@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play games/sec (8x8, 50 MCTS sims/move) on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one process
+per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env).  W untimed
+warmup steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize(), MAX over
+ranks; rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one batch of synthetic input: every rank plays
+`--games` (default 4096 = BASELINE.json configs[1]) complete self-play games from the initial
+position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
+simulations per move, c_puct 1.0, temperature threshold 15 -- entirely on the device, and (N>1)
+the ranks all-gather the replay tuples over RCCL.  value = games completed by all ranks / time.
+
+Extra objects on the same line:
+  roofline     dominant kernel = the fused ResNet trunk (k_trunk): algorithmic FLOPs (378.03 MFLOP per
+               evaluated position) / its summed launch time, measured live with HIP events on
+               the launch stream, against the dense fp16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline the CPU oracle (a C port of the reference algorithm, oracle/) timed on the host cores
+               over a bounded sample of the same workload.  Reported, not targeted.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
+PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+PLIES_PER_GAME = 61.0           # BASELINE.md work model (used only to scale the CPU sample)
+
+
+def cpu_baseline(net, sims, budget_s):
+    """Time the oracle (kind 'port') on the host cores: one independent serial self-play stream per
+    core, bounded to a few plies each, scaled to games/s with the 61-plies-per-game work model."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    onet = ol.Net(net.num_blocks, net.num_filters, ol.state_dict_blob(net.state_dict()))
+    cfg = ol.SelfplayCfg(sims, 15, 1, 1.0, 0.3, 0.25, 1, 0)
+
+    def run(plies):
+        ev, th = C.c_int64(0), C.c_int(0)
+        t0 = time.time()
+        n = ol.lib().orc_cpu_baseline(onet.h, C.byref(cfg), cores, plies, 42, C.byref(ev), C.byref(th))
+        return n, ev.value, th.value, time.time() - t0
+    n, ev, th, dt = run(1)                       # calibration: one ply per stream
+    plies = max(1, min(20, int(budget_s / max(dt, 1e-3))))
+    if plies > 1:
+        n, ev, th, dt = run(plies)
+    return {
+        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th, "kind": "port",
+        "sample": "%d plies (%d network evals) over %d independent games, first %d plies each, "
+                  "10x128 net fp32, %d sims/move, %.1f s; scaled with 61 plies/game"
+                  % (n, ev, cores, plies, sims, dt),
+        "evals_per_s": round(ev / dt, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games (= games per step) per GPU")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--precision", default=None, help="f16x3 (default for 128 filters), f16, f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import othello_reinforcement_learning_test_amd as pkg
+    from othello_reinforcement_learning_test_amd import distributed as D
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    pkg._lib.require_device()   # no GPU => fail loudly
+    import torch.distributed as dist
+
+    torch.manual_seed(42)
+    net = pkg.OthelloResNet(args.blocks, args.filters).eval()
+    ev = pkg.HipResNetEvaluator(net, precision=args.precision)
+    eng = pkg.SearchEngine(args.games, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev)
+    eng.set_timing(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        seed = 42 + 1000003 * (i * world + rank)
+        eng.selfplay_run(args.games, seed, add_noise=True)
+        st, pi, z = eng.selfplay_device_tensors()
+        if world > 1:   # the one exchange step: RCCL all-gather of the replay tuples
+            st, pi, z, _ = D.all_gather_replay(st, pi, z)
+        return int(z.shape[0])
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.time()
+    samples = 0
+    stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0}
+    kt = {"net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0}
+    for i in range(args.steps):
+        samples = step(args.warmup + i)
+        for k, v in eng.counters().items():
+            stats[k] += v
+        for k, v in eng.kernel_time().items():
+            kt[k] += v
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_games = args.games * args.steps * world
+
+    if rank == 0:
+        net_s = kt["net_ms"] * 1e-3
+        flops = stats["evals"] * MFLOP_PER_POSITION * 1e6
+        achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
+        prec = ev.precision
+        out = {
+            "metric": "self-play games/sec (8x8, 50 MCTS sims/move)",
+            "value": round(total_games / dt, 3),
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"f16x3": "f16x3 (fp16 hi/lo operand split on MFMA, fp32 accumulate; fp32-equivalent)",
+                      "f16": "f16 (single fp16 MFMA pass, fp32 accumulate)", "f32": "f32"}[prec],
+            "data": "synthetic",
+            "config": {
+                "workload": "8x8, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank"
+                            % (args.sims, args.blocks, args.filters, args.games),
+                "games_per_step_per_gpu": args.games, "weights": "seeded random init (torch.manual_seed(42)), eval mode",
+                "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
+                "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
+                                                            if world > 1 else "single GPU"),
+                "samples_last_step": samples,
+                "evals_per_game": round(stats["evals"] / max(1, stats["games"]), 1),
+                "plies_per_game": round(stats["plies"] / max(1, stats["games"]), 2),
+            },
+            "roofline": {
+                "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                "launches": kt["net_launches"],
+                "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),
+                "positions_per_launch": round(stats["evals"] / max(1, kt["net_launches"]), 1),
+                "mfma_flops_issued_per_algorithmic_flop": 3 if prec == "f16x3" else 1,
+                "net_time_share": round(net_s / (dt / max(1, 1)) if dt > 0 else 0.0, 4),
+                "tree_kernels_ms": round(kt["tree_ms"], 2),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

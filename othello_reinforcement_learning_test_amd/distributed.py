@@ -1,0 +1,110 @@
+"""Multi-GPU self-play: one process per GPU, games sharded across ranks, ONE exchange step.
+
+Self-play games are independent units (no cross-game state, weights read-only while playing), so the
+path shards with no data-path collective: rank r plays its share of the episodes with its own RNG
+stream.  The only exchange is the end-of-iteration all-gather of the replay tuples
+``(state f32[n,3,8,8], pi f32[n,65], z f32[n])`` so that every (replicated) trainer feeds the same
+``ReplayBuffer`` -- the multi-GPU form of ``replay_buffer.add(training_data)``
+(/root/reference/src/train/trainer.py:185; the reference itself is single-process).
+
+Backend: ``nccl`` (= RCCL over xGMI on ROCm) for CUDA tensors, ``gloo`` for the CPU tests.  Tuple
+counts differ per rank (games have 57-66+ plies), so counts are gathered first and the payload is
+gathered padded to the largest count (one all_gather_into_tensor per array: three large collectives,
+~63 KB per game) and trimmed afterwards.
+"""
+import numpy as np
+
+
+def shard_episodes(num_episodes, rank, world_size):
+    """Round-robin share of rank `rank`: episodes rank, rank+world, ...."""
+    if world_size <= 1:
+        return int(num_episodes)
+    return int((num_episodes - rank + world_size - 1) // world_size) if num_episodes > rank else 0
+
+
+def all_gather_replay(states, pis, zs, group=None):
+    """All-gather variable-length replay tuples.  Inputs are torch tensors on one device (CUDA for
+    RCCL, CPU for gloo) with a common leading length n_r.  Returns (states, pis, zs, counts) where the
+    arrays are the concatenation over ranks in rank order and counts[r] = n_r."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return states, pis, zs, [int(zs.shape[0])]
+    world = dist.get_world_size(group)
+    dev = zs.device
+    n = torch.tensor([zs.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.cpu().tolist()
+    nmax = max(counts)
+    out = []
+    for t in (states, pis, zs):
+        t = t.contiguous()
+        row = t.shape[1:]
+        pad = torch.zeros((nmax,) + tuple(row), dtype=t.dtype, device=dev)
+        pad[: t.shape[0]] = t
+        gathered = torch.empty((world * nmax,) + tuple(row), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, pad, group=group)
+        gathered = gathered.view((world, nmax) + tuple(row))
+        out.append(torch.cat([gathered[r, : counts[r]] for r in range(world)], dim=0))
+    return out[0], out[1], out[2], counts
+
+
+class DistributedSelfPlayWorker:
+    """``execute_episodes`` with the reference's signature for a job of WORLD_SIZE processes: each rank
+    plays ``shard_episodes`` games on its own GPU, then all ranks receive all tuples."""
+
+    def __init__(self, worker, rank=None, world_size=None, base_seed=0, group=None):
+        import torch.distributed as dist
+        self.worker = worker  # a ParallelSelfPlayWorker bound to this rank's GPU
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world_size = dist.get_world_size(group) if world_size is None else world_size
+        self.base_seed = int(base_seed)
+        self._calls = 0
+
+    def execute_episodes_tensors(self, num_episodes, add_dirichlet_noise=True):
+        """-> CUDA tensors (states, pis, zs) of the WHOLE job, plus per-rank tuple counts."""
+        mine = shard_episodes(num_episodes, self.rank, self.world_size)
+        eng = self.worker.engine
+        self.worker.batch_mcts.evaluator.refresh()
+        seed = (self.base_seed + 0x9E3779B97F4A7C15 * (self._calls * self.world_size + self.rank + 1)) % 2**63
+        self._calls += 1
+        import torch
+        if mine > 0:
+            eng.selfplay_run(mine, seed, add_dirichlet_noise)
+            st, pi, z = eng.selfplay_device_tensors()
+        else:
+            st = torch.empty((0, 3, 8, 8), dtype=torch.float32, device="cuda")
+            pi = torch.empty((0, 65), dtype=torch.float32, device="cuda")
+            z = torch.empty((0,), dtype=torch.float32, device="cuda")
+        return all_gather_replay(st, pi, z, self.group)
+
+    def execute_episodes(self, num_episodes, add_dirichlet_noise=True):
+        st, pi, z, _ = self.execute_episodes_tensors(num_episodes, add_dirichlet_noise)
+        st, pi, z = st.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+        return [(st[i].copy(), pi[i].copy(), float(z[i])) for i in range(len(z))]
+
+
+def init_from_env(backend=None):
+    """torch.distributed init from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun).  Returns
+    (rank, world_size, local_rank).  Single process when WORLD_SIZE is absent or 1."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    return rank, world, local
