@@ -8,7 +8,7 @@
 //     the activations NEVER leave the CU: they live in LDS as [cell][hi 128 x f16 | lo 128 x f16]
 //     (512 B per cell, 128 KiB per tile) and every 3x3 tap reads them in place (implicit GEMM, no
 //     im2col copy); out-of-board taps read a zeroed cell.
-//   * wave w owns output channels [32w, 32w+32): its B operand (weights) streams from L2 straight
+//   * wave w owns output channels [32w, 32w+32): its weight operand streams from L2 straight
 //     into registers in MFMA fragment order (host-packed, 1 KiB per wave-load, every byte loaded
 //     exactly once per workgroup and layer); accumulators (8 tiles of 32x32) and the fp32 residual
 //     stay in registers, so there is no barrier inside a layer -- two per layer around the
@@ -19,8 +19,9 @@
 //     general).  OTH_PREC_F16 runs the same kernel with the hi parts only.
 //   * power-of-two scaling of activations (2^4) and of each layer's weights keeps the lo parts in
 //     the normal f16 range; it is undone exactly on the fp32 accumulator.
-//   * LDS bank conflicts: the 16-byte chunk index of a cell is XORed with (x&3)|((y&3)<<2); the 16
-//     lanes of every ds_read_b128 group then hit 16 different slots for all nine taps.
+//   * LDS bank conflicts: the 16-byte chunk index of a cell is XORed with (x&7)|((y&1)<<3); the 16
+//     lanes of every ds_read_b128 group (all nine taps) and of every ds_write_b64 group then hit 16
+//     different slots.
 #include <math.h>
 #include <string.h>
 
@@ -33,6 +34,7 @@ namespace oth {
 
 using half8 = _Float16 __attribute__((ext_vector_type(8)));
 using f32x16 = float __attribute__((ext_vector_type(16)));
+using half4 = _Float16 __attribute__((ext_vector_type(4)));
 
 constexpr int kTilePos = 4;                    // positions per workgroup
 constexpr int kCellBytes = 512;                // 256 B hi + 256 B lo
@@ -63,12 +65,17 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// LDS address of this lane's activation fragment: cell base (or the zero cell) | swizzled 16-B chunk
+#define OTH_AFRAG(q) (lds + (A[(q) & 7] | ((((uint32_t)(((q) >> 3) << 1)) ^ hk) << 4)))
+
 template <bool X3>
 __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __restrict__ sb,
                                                   const uint64_t* __restrict__ ob,
                                                   const uint64_t* __restrict__ lgl, int64_t n,
                                                   const int32_t* __restrict__ n_valid, float* __restrict__ logp,
                                                   float* __restrict__ vout) {
+    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
+    constexpr int PB = X3 ? 2 : 4;  // weight fragments in flight (k-steps)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int64_t nv = n;
     if (n_valid) {
@@ -109,6 +116,9 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     }
     __syncthreads();
 
+    // MFMA roles: A operand = weights (rows = 32 output channels of this wave), B operand =
+    // activations (columns = the 32 cells of a tile).  D[m][n]: lane holds column n = r (its cell) and
+    // rows m = (i&3) + 8*(i>>2) + 4*h, i.e. four groups of 4 CONSECUTIVE channels -> 8-byte LDS stores.
     f32x16 acc[8], res[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -120,59 +130,85 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const uint4* wp = a.stem + ((size_t)(kk * 4 + wave) * 2) * 64 + lane;
-            const uint4 bh4 = wp[0], bl4 = wp[64];
-            const half8 bh = __builtin_bit_cast(half8, bh4), bl = __builtin_bit_cast(half8, bl4);
+            const uint4 wh4 = wp[0], wl4 = wp[64];
+            const half8 wh = __builtin_bit_cast(half8, wh4), wlo = __builtin_bit_cast(half8, wl4);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const half8 ah = *(const half8*)(lds + kScratchOff + (t * 32 + r) * 64 + (kk * 2 + h) * 16);
-                if (X3) acc[t] = mfma16(ah, bl, acc[t]);
-                acc[t] = mfma16(ah, bh, acc[t]);
+                const half8 xh = *(const half8*)(lds + kScratchOff + (t * 32 + r) * 64 + (kk * 2 + h) * 16);
+                if (X3) acc[t] = mfma16(wlo, xh, acc[t]);
+                acc[t] = mfma16(wh, xh, acc[t]);
             }
         }
     }
 
-    // write-side constants of this lane: output channel n, its 16-byte chunk and byte offset in the chunk
-    const int n_out = wave * 32 + r;
-    const int chunk_n = n_out >> 3;
-    const uint32_t wr_lane = (uint32_t)(4 * h) * kCellBytes + (uint32_t)(n_out & 7) * 2;
+    // write-side constants: this lane's cell within a tile is r; its swizzle key; per channel group g
+    // the byte offset of the 8-byte half-chunk holding channels wave*32 + 8g + 4h .. +3
+    const uint32_t keyw = (uint32_t)((r & 7) | (((r >> 3) & 1) << 3));
+    uint32_t wr_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        wr_off[g] = (uint32_t)r * kCellBytes + ((((uint32_t)(wave * 4 + g)) ^ keyw) << 4) + 8u * (uint32_t)h;
+    const int ch0 = wave * 32 + 4 * h;  // + 8g + e
 
     const int n_layers = 1 + a.n_res_layers;
     for (int layer = 0; layer < n_layers; ++layer) {
         // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split
-        const float bias_n = a.bias[layer * 128 + n_out];
+        float4 b4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4[g] = *(const float4*)(a.bias + layer * 128 + ch0 + 8 * g);
         const float inv = a.inv[layer];
         const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
         const bool set_res = layer == 0 || add_res;
+        const bool last = layer == n_layers - 1;
         __syncthreads();  // every wave has finished reading the previous activations
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = fmaf(acc[t][i], inv, bias_n);
-                if (add_res) v += res[t][i];
-                v = v > 0.f ? v : 0.f;
-                if (set_res) res[t][i] = v;
-                acc[t][i] = 0.f;
-                const float vs = fminf(v * kActScale, 60000.0f);
-                const _Float16 hi = (_Float16)vs;
-                const uint32_t cell_off = (uint32_t)(t * 32 + (i & 3) + 8 * (i >> 2)) * kCellBytes;
-                const uint32_t addr = cell_off + wr_lane + (uint32_t)((chunk_n ^ i) << 4);
-                *(_Float16*)(lds + addr) = hi;
-                if (X3) *(_Float16*)(lds + addr + 256) = (_Float16)(vs - (float)hi);
+            for (int g = 0; g < 4; ++g) {
+                float vs[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e;
+                    const float bb = e == 0 ? b4[g].x : (e == 1 ? b4[g].y : (e == 2 ? b4[g].z : b4[g].w));
+                    float v = fmaf(acc[t][i], inv, bb);
+                    if (add_res) v += res[t][i];
+                    v = v > 0.f ? v : 0.f;
+                    if (set_res) res[t][i] = v;
+                    acc[t][i] = 0.f;
+                    vs[e] = fminf(v * kActScale, 60000.0f);
+                }
+                if (!last) {
+                    half4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
+                    char* dst = lds + (uint32_t)(t * 32) * kCellBytes + wr_off[g];
+                    *(half4*)dst = hi;
+                    if (X3) {
+                        half4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(vs[e] - (float)hi[e]);
+                        *(half4*)(dst + 256) = lo;
+                    }
+                }
             }
         }
+        if (last) break;
         __syncthreads();
-        if (layer == n_layers - 1) break;
 
         // ---------------- conv `layer+1`: 9 taps x 8 k-steps of 16 input channels
-        const uint4* wl = a.w + ((size_t)layer * 72 * 4 + wave) * 128 + lane;  // + step*4*128
-        uint4 bh4 = wl[0], bl4 = wl[64];
+        const uint4* wl = a.w + ((size_t)layer * 72 * 4 + wave) * 128 + lane;  // + step*512 (+64: lo)
+        uint4 wq_h[PB], wq_l[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            wq_h[i] = wl[(size_t)i * 512];
+            if (X3) wq_l[i] = wl[(size_t)i * 512 + 64];
+        }
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            // per-tile base address of this lane's source cell (or the zero cell)
+            // per-tile base address of this lane's source cell (or the zero cell) and the chunk swizzle
             const int yo = (r >> 3) + dy, xs = (r & 7) + dx;   // yo relative to the tile's first row
             const bool xok = xs >= 0 && xs < 8;
-            const uint32_t hk = (uint32_t)(h ^ ((xs & 3) | ((yo & 3) << 2)));
+            const uint32_t hk = (uint32_t)(h ^ ((xs & 7) | ((yo & 1) << 3)));
             uint32_t A[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -180,37 +216,49 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                 const bool ok = xok && ys >= 0 && ys < 8;
                 A[t] = ok ? (uint32_t)((t >> 1) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)kZeroOff;
             }
-#pragma unroll 2
-            for (int kk = 0; kk < 8; ++kk) {
-                const half8 bh = __builtin_bit_cast(half8, bh4), bl = __builtin_bit_cast(half8, bl4);
-                // prefetch the next step's fragments (the last step of a layer re-reads its own: harmless)
-                const int step = tap * 8 + kk;
-                const int nstep = step + 1 < 72 ? step + 1 : step;
-                bh4 = wl[(size_t)nstep * 512];
-                bl4 = wl[(size_t)nstep * 512 + 64];
-                const uint32_t off = (((uint32_t)(kk << 1)) ^ hk) << 4;
+            // software pipeline over q = kk*8 + t: fragment q+PD is requested before the MFMAs of q
+            half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const char* p = lds + (A[t] | off);
-                    const half8 ah = *(const half8*)p;
-                    if (X3) {
-                        const half8 al = *(const half8*)(p + 256);
-                        acc[t] = mfma16(al, bh, acc[t]);
-                        acc[t] = mfma16(ah, bl, acc[t]);
-                    }
-                    acc[t] = mfma16(ah, bh, acc[t]);
+            for (int q = 0; q < PD; ++q) {
+                xh[q] = *(const half8*)OTH_AFRAG(q);
+                if (X3) xl[q] = *(const half8*)(OTH_AFRAG(q) + 256);
+            }
+            half8 wh, wlo;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                if (q + PD < 64) {
+                    xh[(q + PD) % (PD + 1)] = *(const half8*)OTH_AFRAG(q + PD);
+                    if (X3) xl[(q + PD) % (PD + 1)] = *(const half8*)(OTH_AFRAG(q + PD) + 256);
                 }
+                if ((q & 7) == 0) {  // new k-step: take its weight fragments, refill the ring slot
+                    const int kk = q >> 3, slot = kk % PB;
+                    wh = __builtin_bit_cast(half8, wq_h[slot]);
+                    if (X3) wlo = __builtin_bit_cast(half8, wq_l[slot]);
+                    int nstep = tap * 8 + kk + PB;
+                    nstep = nstep < 72 ? nstep : 71;  // tail: re-read the last fragment (harmless)
+                    wq_h[slot] = wl[(size_t)nstep * 512];
+                    if (X3) wq_l[slot] = wl[(size_t)nstep * 512 + 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above ahead of the MFMAs below
+                const int t = q & 7;
+                if (X3) {
+                    acc[t] = mfma16(wh, xl[q % (PD + 1)], acc[t]);
+                    acc[t] = mfma16(wlo, xh[q % (PD + 1)], acc[t]);
+                }
+                acc[t] = mfma16(wh, xh[q % (PD + 1)], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
     // ---------------- heads (fp32 VALU): final activations (in `res`) -> LDS [256 cells][128] f32
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int cell = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            *(float*)(lds + (size_t)cell * 512 + n_out * 4) = res[t][i];
+        for (int g = 0; g < 4; ++g) {
+            const float4 o = make_float4(res[t][4 * g], res[t][4 * g + 1], res[t][4 * g + 2], res[t][4 * g + 3]);
+            *(float4*)(lds + (size_t)(t * 32 + r) * 512 + (size_t)(ch0 + 8 * g) * 4) = o;
         }
     __syncthreads();
     for (int p = 0; p < kTilePos; ++p) {
