@@ -39,7 +39,10 @@ def cpu_baseline(net, sims, budget_s):
     core, bounded to a few plies each, scaled to games/s with the 61-plies-per-game work model."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     onet = ol.Net(net.num_blocks, net.num_filters, ol.state_dict_blob(net.state_dict()))
     cfg = ol.SelfplayCfg(sims, 15, 1, 1.0, 0.3, 0.25, 1, 0)
 

@@ -1,0 +1,75 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the episode sharding and the variable-length
+replay all-gather (the only exchange step of the multi-GPU path; RCCL on the GPU box)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from othello_reinforcement_learning_test_amd.distributed import all_gather_replay, shard_episodes
+
+
+def test_shard_episodes_partitions_exactly():
+    for world in (1, 2, 3, 4, 8):
+        for n in (0, 1, 5, 7, 8, 100, 4096, 4099):
+            shares = [shard_episodes(n, r, world) for r in range(world)]
+            assert sum(shares) == n and max(shares) - min(shares) <= 1
+            assert shares == sorted(shares, reverse=True)   # round-robin: low ranks get the remainder
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(rank, n):
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    st = torch.from_numpy((rng.random((n, 3, 8, 8)) < 0.3).astype(np.float32))
+    pi = torch.from_numpy(rng.random((n, 65)).astype(np.float32))
+    z = torch.from_numpy(rng.integers(-1, 2, n).astype(np.float32))
+    return st, pi, z
+
+
+def _worker(rank, world, port, counts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st, pi, z = _make(rank, counts[rank])
+        gs, gp, gz, got = all_gather_replay(st, pi, z)
+        ok = got == list(counts)
+        exp = [_make(r, counts[r]) for r in range(world)]
+        ok &= torch.equal(gs, torch.cat([e[0] for e in exp]))
+        ok &= torch.equal(gp, torch.cat([e[1] for e in exp]))
+        ok &= torch.equal(gz, torch.cat([e[2] for e in exp]))
+        q.put((rank, bool(ok), int(gz.shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(61, 64), (120, 0), (1, 300)])
+def test_all_gather_replay_gloo_world2(counts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, n in res:
+        assert ok and n == sum(counts), (rank, ok, n)
+
+
+def test_single_process_is_identity():
+    st, pi, z = _make(0, 10)
+    a, b, c, counts = all_gather_replay(st, pi, z)
+    assert a is st and b is pi and c is z and counts == [10]
