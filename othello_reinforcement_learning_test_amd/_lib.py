@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libothello_mi355x.so")
+# OTHELLO_MI355X_LIB: A/B-testing hook for kernel work (another build of the same library)
+LIB_PATH = os.environ.get("OTHELLO_MI355X_LIB") or os.path.join(_HERE, "libothello_mi355x.so")
 
 OTH_PREC_F32, OTH_PREC_F16X3, OTH_PREC_F16 = 0, 1, 2
 PRECISIONS = {"f32": OTH_PREC_F32, "f16x3": OTH_PREC_F16X3, "f16": OTH_PREC_F16}

@@ -48,8 +48,8 @@ struct MfmaWeights {
     int blocks = 0;
     uint4* d_w = nullptr;      // fragments: [layer][step 0..71][wave 0..3][plane hi,lo][64 lanes] x 16 B
     uint4* d_stem = nullptr;   // [step 0..1][wave][plane][64 lanes]
-    float* d_bias = nullptr;   // [1 + 2*blocks][128]
-    float* d_inv = nullptr;    // [1 + 2*blocks] 1 / (weight_scale * act_scale)
+    float* d_bias = nullptr;   // [1 + 2*blocks][128], pre-multiplied by kActScale
+    float* d_inv = nullptr;    // [1 + 2*blocks] 1 / weight_scale
 };
 
 struct MfmaArgs {
@@ -66,7 +66,7 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 }
 
 // LDS address of this lane's activation fragment: cell base (or the zero cell) | swizzled 16-B chunk
-#define OTH_AFRAG(q) (lds + (A[(q) & 7] | ((((uint32_t)(((q) >> 3) << 1)) ^ hk) << 4)))
+#define OTH_AFRAG(AA, HK, q) (lds + ((AA)[(q) & 7] | ((((uint32_t)(((q) >> 3) << 1)) ^ (HK)) << 4)))
 
 template <bool X3>
 __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __restrict__ sb,
@@ -150,8 +150,21 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
         wr_off[g] = (uint32_t)r * kCellBytes + ((((uint32_t)(wave * 4 + g)) ^ keyw) << 4) + 8u * (uint32_t)h;
     const int ch0 = wave * 32 + 4 * h;  // + 8g + e
 
+    // Activations and the residual are carried PRE-SCALED by kActScale (ReLU commutes with a positive
+    // scale): res16 = 16 * x.  bias16/inv16 are prepared on the host.
     const int n_layers = 1 + a.n_res_layers;
+    uint4 wq_h[PB], wq_l[PB];  // weight-fragment ring of the conv that FOLLOWS the current epilogue
     for (int layer = 0; layer < n_layers; ++layer) {
+        const bool last = layer == n_layers - 1;
+        // request the first weight fragments of conv `layer+1` now: their L2 latency hides under the epilogue
+        const uint4* wl = a.w + ((size_t)layer * 72 * 4 + wave) * 128 + lane;  // + step*512 (+64: lo)
+        if (!last) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                wq_h[i] = wl[(size_t)i * 512];
+                if (X3) wq_l[i] = wl[(size_t)i * 512 + 64];
+            }
+        }
         // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split
         float4 b4[4];
 #pragma unroll
@@ -159,7 +172,6 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
         const float inv = a.inv[layer];
         const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
         const bool set_res = layer == 0 || add_res;
-        const bool last = layer == n_layers - 1;
         __syncthreads();  // every wave has finished reading the previous activations
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -172,10 +184,10 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                     const float bb = e == 0 ? b4[g].x : (e == 1 ? b4[g].y : (e == 2 ? b4[g].z : b4[g].w));
                     float v = fmaf(acc[t][i], inv, bb);
                     if (add_res) v += res[t][i];
-                    v = v > 0.f ? v : 0.f;
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, 60000.f);  // ReLU + f16 range clamp (x <= 3750)
                     if (set_res) res[t][i] = v;
                     acc[t][i] = 0.f;
-                    vs[e] = fminf(v * kActScale, 60000.0f);
+                    vs[e] = v;
                 }
                 if (!last) {
                     half4 hi;
@@ -195,40 +207,46 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
         if (last) break;
         __syncthreads();
 
-        // ---------------- conv `layer+1`: 9 taps x 8 k-steps of 16 input channels
-        const uint4* wl = a.w + ((size_t)layer * 72 * 4 + wave) * 128 + lane;  // + step*512 (+64: lo)
-        uint4 wq_h[PB], wq_l[PB];
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            wq_h[i] = wl[(size_t)i * 512];
-            if (X3) wq_l[i] = wl[(size_t)i * 512 + 64];
-        }
-        for (int tap = 0; tap < 9; ++tap) {
+        // ---------------- conv `layer+1`: 9 taps x 8 k-steps of 16 input channels, one software pipeline
+        // over all 576 (tap, k-step, tile) fragments: fragment q+PD is requested before the MFMAs of q,
+        // across tap boundaries too.
+        uint32_t A[8], An[8];
+        uint32_t hk, hkn;
+        // lane-constant tap geometry
+        auto tap_setup = [&](int tap, uint32_t(&Ao)[8], uint32_t& hko) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            // per-tile base address of this lane's source cell (or the zero cell) and the chunk swizzle
             const int yo = (r >> 3) + dy, xs = (r & 7) + dx;   // yo relative to the tile's first row
             const bool xok = xs >= 0 && xs < 8;
-            const uint32_t hk = (uint32_t)(h ^ ((xs & 7) | ((yo & 1) << 3)));
-            uint32_t A[8];
+            hko = (uint32_t)(h ^ ((xs & 7) | ((yo & 1) << 3)));
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int ys = (t & 1) * 4 + yo;
                 const bool ok = xok && ys >= 0 && ys < 8;
-                A[t] = ok ? (uint32_t)((t >> 1) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)kZeroOff;
+                Ao[t] = ok ? (uint32_t)((t >> 1) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)kZeroOff;
             }
-            // software pipeline over q = kk*8 + t: fragment q+PD is requested before the MFMAs of q
-            half8 xh[PD + 1], xl[PD + 1];
+        };
+        tap_setup(0, A, hk);
+        half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                xh[q] = *(const half8*)OTH_AFRAG(q);
-                if (X3) xl[q] = *(const half8*)(OTH_AFRAG(q) + 256);
-            }
+        for (int q = 0; q < PD; ++q) {
+            xh[q] = *(const half8*)OTH_AFRAG(A, hk, q);
+            if (X3) xl[q] = *(const half8*)(OTH_AFRAG(A, hk, q) + 256);
+        }
+        for (int tap = 0; tap < 9; ++tap) {
+            tap_setup(tap < 8 ? tap + 1 : 8, An, hkn);  // next tap's geometry (last tap: harmless re-reads)
             half8 wh, wlo;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
-                if (q + PD < 64) {
-                    xh[(q + PD) % (PD + 1)] = *(const half8*)OTH_AFRAG(q + PD);
-                    if (X3) xl[(q + PD) % (PD + 1)] = *(const half8*)(OTH_AFRAG(q + PD) + 256);
+                {   // prefetch fragment q+PD (slot rotation: 64 % (PD+1) tiles per tap)
+                    const int qq = q + PD;
+                    const int slot = (q + PD) % (PD + 1);
+                    if (qq < 64) {
+                        xh[slot] = *(const half8*)OTH_AFRAG(A, hk, qq);
+                        if (X3) xl[slot] = *(const half8*)(OTH_AFRAG(A, hk, qq) + 256);
+                    } else {
+                        xh[slot] = *(const half8*)OTH_AFRAG(An, hkn, qq - 64);
+                        if (X3) xl[slot] = *(const half8*)(OTH_AFRAG(An, hkn, qq - 64) + 256);
+                    }
                 }
                 if ((q & 7) == 0) {  // new k-step: take its weight fragments, refill the ring slot
                     const int kk = q >> 3, slot = kk % PB;
@@ -248,6 +266,20 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                 acc[t] = mfma16(wh, xh[q % (PD + 1)], acc[t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // rotate: the ring slots continue seamlessly only if 64 % (PD+1) == 0; otherwise re-base them
+            if constexpr (64 % (PD + 1) != 0) {
+                half8 th[PD + 1], tl[PD + 1];
+#pragma unroll
+                for (int i = 0; i < PD + 1; ++i) { th[i] = xh[i]; if (X3) tl[i] = xl[i]; }
+#pragma unroll
+                for (int i = 0; i < PD; ++i) {
+                    xh[i] = th[(64 + i) % (PD + 1)];
+                    if (X3) xl[i] = tl[(64 + i) % (PD + 1)];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) A[t] = An[t];
+            hk = hkn;
         }
     }
 
@@ -257,7 +289,9 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 o = make_float4(res[t][4 * g], res[t][4 * g + 1], res[t][4 * g + 2], res[t][4 * g + 3]);
+            const float us = 1.0f / kActScale;
+            const float4 o = make_float4(res[t][4 * g] * us, res[t][4 * g + 1] * us, res[t][4 * g + 2] * us,
+                                         res[t][4 * g + 3] * us);
             *(float4*)(lds + (size_t)(t * 32 + r) * 512 + (size_t)(ch0 + 8 * g) * 4) = o;
         }
     __syncthreads();
@@ -331,15 +365,15 @@ int mfma_pack_weights(oth_net* net, int precision) {
         std::vector<int> km(32, -1);
         for (int k = 0; k < 27; ++k) km[k] = k;
         const float sc = pack_conv(hn.stem, 32, stem, 0, 2, km);
-        inv[0] = 1.0f / (sc * kActScale);
-        memcpy(&bias[0], hn.stem.bias.data(), 128 * sizeof(float));
+        inv[0] = 1.0f / sc;  // accumulator holds (16 x) * (sc w): divide by sc to get 16 * y
+        for (int i = 0; i < 128; ++i) bias[i] = hn.stem.bias[i] * kActScale;
     }
     std::vector<int> km(1152);
     for (int k = 0; k < 1152; ++k) km[k] = k;  // k = tap*128 + ci, steps ordered (tap, kk)
     for (int l = 0; l < L; ++l) {
         const float sc = pack_conv(hn.res[l], 1152, w, (size_t)l * layer_halfs, 72, km);
-        inv[l + 1] = 1.0f / (sc * kActScale);
-        memcpy(&bias[(size_t)(l + 1) * 128], hn.res[l].bias.data(), 128 * sizeof(float));
+        inv[l + 1] = 1.0f / sc;
+        for (int i = 0; i < 128; ++i) bias[(size_t)(l + 1) * 128 + i] = hn.res[l].bias[i] * kActScale;
     }
     OTH_HIP(hipMalloc(&mw->d_w, w.size() * 2));
     OTH_HIP(hipMalloc(&mw->d_stem, stem.size() * 2));
