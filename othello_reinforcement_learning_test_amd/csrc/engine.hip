@@ -99,72 +99,108 @@ __device__ __forceinline__ void backup_path(Edge* edges, const PathT* path, int 
     }
 }
 
-// queue a position for evaluation; returns the batch slot (lane-uniform; lane 0 does the atomic)
-__device__ __forceinline__ int queue_eval(const Dev& d, uint64_t sb, uint64_t ob, uint64_t lg, int lane) {
-    int slot = 0;
+// Evaluation-batch slots are handed out per BLOCK: the 4 games of a block post whether they need a
+// slot, thread 0 does ONE atomicAdd for the block (4096 same-address atomics per launch serialised
+// to ~90 us; 1024 take ~12 us) and the waves take consecutive slots.  Event counters are kept per block
+// (plain adds to the block's own row, summed on the host at the end of a run).
+// Every thread of the block must call this (it contains barriers).
+struct BlockTally {
+    int need[4];
+    int base;
+};
+__device__ __forceinline__ int block_alloc_eval(const Dev& d, BlockTally& bt, bool need, int n_sims, int n_term,
+                                                int n_plies, int n_games) {
+    __shared__ int s_cnt[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
-        slot = atomicAdd(d.n_eval, 1);
+        bt.need[wave] = need ? 1 : 0;
+        s_cnt[wave][0] = n_sims; s_cnt[wave][1] = n_term; s_cnt[wave][2] = n_plies; s_cnt[wave][3] = n_games;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = bt.need[0] + bt.need[1] + bt.need[2] + bt.need[3];
+        bt.base = total ? atomicAdd(d.n_eval, total) : 0;
+        unsigned long long* c = d.counters + (size_t)blockIdx.x * 8;
+        c[0] += (unsigned long long)total;
+        c[1] += (unsigned long long)(s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0]);
+        c[5] += (unsigned long long)(s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]);
+        c[2] += (unsigned long long)(s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]);
+        c[3] += (unsigned long long)(s_cnt[0][3] + s_cnt[1][3] + s_cnt[2][3] + s_cnt[3][3]);
+    }
+    __syncthreads();
+    int slot = bt.base;
+    for (int w = 0; w < wave; ++w) slot += bt.need[w];
+    return slot;
+}
+
+__device__ __forceinline__ void write_eval(const Dev& d, int slot, uint64_t sb, uint64_t ob, uint64_t lg, int lane) {
+    if (lane == 0) {
         d.ev_self[slot] = sb;
         d.ev_opp[slot] = ob;
         d.ev_legal[slot] = lg;
-        atomicAdd(&d.counters[0], 1ULL);
     }
-    return __shfl(slot, 0);
 }
 
 // ---- K1a: select (node.py:91-126, parallel_self_play.py:172-197) ----------------------------------
 __global__ __launch_bounds__(256) void k_select(Dev d) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= d.n_slots || !d.g_active[g]) return;
     extern __shared__ uint32_t lds_path_all[];  // [4 waves][cap_path]: the path of the current descent
+    __shared__ BlockTally bt;
     volatile uint32_t* lpath = lds_path_all + (threadIdx.x >> 6) * d.cap_path;
-    Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
-    Edge* edges = d.edges + (size_t)g * d.cap_edges;
-    uint32_t* path = d.path + (size_t)g * d.cap_path;
-    int node = 0, pv = 0, depth = 0;
-    uint64_t sb = nodes[0].self_b, ob = nodes[0].opp_b;
-    for (;;) {
-        const Node nd = nodes[node];
-        const bool pass = nd.legal == 0;
-        const bool act = pass ? (lane == 0) : ((nd.legal >> lane) & 1ULL);
-        const int rank = __popcll(nd.legal & ((1ULL << lane) - 1ULL));
-        const int ei = (int)nd.edge_base + rank;
-        double score = -INFINITY;
-        int e_n = 0, e_child = 0;
-        if (act) {
-            const Edge e = edges[ei];
-            e_n = e.n;
-            e_child = e.child;
-            const double q = e.n == 0 ? 0.0 : e.w / (double)e.n;          // node.py:51-60
-            const float cp_p = d.c_puct * e.prior;                       // float32 product (weak python scalar)
-            const double u = (double)cp_p * d.sqrt_tab[pv] / (double)(1 + e.n);  // node.py:116
-            score = q + u;                                               // node.py:119
+    const bool live = g < d.n_slots && d.g_active[g];
+    bool need = false, terminal = false;
+    uint64_t sb = 0, ob = 0, lg = 0;
+    int depth = 0;
+    Edge* edges = nullptr;
+    uint32_t* path = nullptr;
+    if (live) {
+        Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
+        edges = d.edges + (size_t)g * d.cap_edges;
+        path = d.path + (size_t)g * d.cap_path;
+        int node = 0, pv = 0;
+        sb = nodes[0].self_b;
+        ob = nodes[0].opp_b;
+        for (;;) {
+            const Node nd = nodes[node];
+            const bool pass = nd.legal == 0;
+            const bool act = pass ? (lane == 0) : ((nd.legal >> lane) & 1ULL);
+            const int rank = __popcll(nd.legal & ((1ULL << lane) - 1ULL));
+            const int ei = (int)nd.edge_base + rank;
+            double score = -INFINITY;
+            int e_n = 0, e_child = 0;
+            if (act) {
+                const Edge e = edges[ei];
+                e_n = e.n;
+                e_child = e.child;
+                const double q = e.n == 0 ? 0.0 : e.w / (double)e.n;          // node.py:51-60
+                const float cp_p = d.c_puct * e.prior;                       // float32 product (weak python scalar)
+                const double u = (double)cp_p * d.sqrt_tab[pv] / (double)(1 + e.n);  // node.py:116
+                score = q + u;                                               // node.py:119
+            }
+            const double best = wave_max_f64(score);
+            const unsigned long long eq = __ballot(act && score == best);
+            const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
+            const int action = pass ? 64 : L;
+            const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
+            if (lane == 0) lpath[depth] = (uint32_t)ce;
+            ++depth;
+            apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
+            if (child == 0) break;        // that child has no children yet: leaf
+            pv = nvis;
+            node = child;
         }
-        const double best = wave_max_f64(score);
-        const unsigned long long eq = __ballot(act && score == best);
-        const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
-        const int action = pass ? 64 : L;
-        const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
-        if (lane == 0) lpath[depth] = (uint32_t)ce;
-        ++depth;
-        apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
-        if (child == 0) break;        // that child has no children yet: leaf
-        pv = nvis;
-        node = child;
+        lg = legal_moves(sb, ob);
+        terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
+        need = !terminal;
     }
-    const uint64_t lg = legal_moves(sb, ob);
-    const bool terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
-    if (lane == 0) atomicAdd(&d.counters[1], 1ULL);
-    __builtin_amdgcn_wave_barrier();
+    const int slot = block_alloc_eval(d, bt, need, live ? 1 : 0, terminal ? 1 : 0, 0, 0);
+    if (!live) return;
     if (terminal) {  // parallel_self_play.py:133-135: back up float(get_winner()) immediately
         backup_path(edges, lpath, depth, (double)winner(sb, ob), lane, 0);
-        if (lane == 0) {
-            d.pend[g] = PEND_NONE;
-            atomicAdd(&d.counters[5], 1ULL);
-        }
+        if (lane == 0) d.pend[g] = PEND_NONE;
     } else {
-        const int slot = queue_eval(d, sb, ob, lg, lane);
+        write_eval(d, slot, sb, ob, lg, lane);
         for (int i = lane; i < depth; i += 64) path[i] = lpath[i];  // for k_expand (next launch)
         if (lane == 0) {
             d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
@@ -251,10 +287,10 @@ __device__ inline double philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1)
     return ((double)(x0 >> 5) * 67108864.0 + (double)(x1 >> 6)) / 9007199254740992.0;
 }
 
-// (re)start the search of slot g from position (sb, ob): empty tree, root queued for evaluation
-__device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uint64_t ob, int lane) {
-    const uint64_t lg = legal_moves(sb, ob);
-    const int slot = queue_eval(d, sb, ob, lg, lane);
+// (re)start the search of slot g from position (sb, ob): empty tree, root written to batch slot `slot`
+__device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uint64_t ob, uint64_t lg, int slot,
+                                           int lane) {
+    write_eval(d, slot, sb, ob, lg, lane);
     if (lane == 0) {
         d.n_nodes[g] = 0;
         d.n_edges[g] = 0;
@@ -267,23 +303,31 @@ __device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uin
 
 __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __restrict__ sb,
                                                       const uint64_t* __restrict__ ob, int n) {
+    __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = g < n;
+    uint64_t s0 = 0, o0 = 0;
+    if (live) { s0 = sb[g]; o0 = ob[g]; }
+    const int slot = block_alloc_eval(d, bt, live, 0, 0, 0, 0);
     if (g >= d.n_slots) return;
-    if (g >= n) {
+    if (!live) {
         if (lane == 0) { d.g_active[g] = 0; d.pend[g] = PEND_NONE; }
         return;
     }
-    if (lane == 0) { d.g_active[g] = 1; d.g_self[g] = sb[g]; d.g_opp[g] = ob[g]; }
-    begin_root(d, g, sb[g], ob[g], lane);
+    if (lane == 0) { d.g_active[g] = 1; d.g_self[g] = s0; d.g_opp[g] = o0; }
+    begin_root(d, g, s0, o0, legal_moves(s0, o0), slot, lane);
 }
 
 // start games: slot g gets game id g (or stays idle), ply 0, start position, root queued
 __global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
+    __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = g < n_start;
+    const int slot = block_alloc_eval(d, bt, live, 0, 0, 0, 0);
     if (g >= d.n_slots) return;
-    if (g >= n_start) {
+    if (!live) {
         if (lane == 0) { d.g_active[g] = 0; d.g_id[g] = -1; d.pend[g] = PEND_NONE; }
         return;
     }
@@ -292,7 +336,7 @@ __global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
         d.g_self[g] = kStartSelf; d.g_opp[g] = kStartOpp;
         atomicAdd(d.n_active, 1);
     }
-    begin_root(d, g, kStartSelf, kStartOpp, lane);
+    begin_root(d, g, kStartSelf, kStartOpp, legal_moves(kStartSelf, kStartOpp), slot, lane);
 }
 
 // ---- K4: ply step (node.py:147-182, parallel_self_play.py:374-397, self_play.py:101-117) ---------
@@ -300,85 +344,99 @@ __global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
 // ply < threshold, else first argmax), play it, detect the end of the game, refill the slot, and
 // queue the next root.  forced != nullptr: play forced[g] instead (host-driven lock-step mode).
 __global__ __launch_bounds__(256) void k_ply(Dev d, const int32_t* __restrict__ forced, int refill) {
+    __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= d.n_slots || !d.g_active[g]) return;
-    const Node root = d.nodes[(size_t)g * d.cap_nodes];
-    const Edge* edges = d.edges + (size_t)g * d.cap_edges;
-    const bool pass = root.legal == 0;
-    const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
-    const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
-    int n = act ? (int)edges[root.edge_base + rank].n : 0;
-    const int n64 = pass ? (int)edges[root.edge_base].n : 0;
-    const int total = wave_sum_i32(n) + n64;
-    // counts / counts.sum() in float32 (node.py:175-177 with temperature 1)
-    const float tot_f = (float)total;
-    float pi = act ? (float)n / tot_f : 0.0f;
-    float pi64 = pass ? (float)n64 / tot_f : 0.0f;
-    // first maximum of the visit counts (np.argmax)
-    const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
-    const unsigned long long eqm = __ballot(act && n == best_n);
-    const int amax = pass ? 64 : (__ffsll(eqm) - 1);
-    const int ply = d.g_ply[g], gid = d.g_id[g];
-    const bool sample = ply < d.temp_threshold;
-    int action;
-    if (forced) {
-        action = forced[g];
-    } else if (!sample) {
-        action = amax;
-    } else {
-        // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
-        const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
-        double c = 0.0;
-        double cdf_lane = 0.0;
-        for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
-            c += (double)__shfl(pi, i);
-            if (i == lane) cdf_lane = c;
+    const bool live = g < d.n_slots && d.g_active[g];
+    bool next_root = false, over = false;
+    uint64_t sb = 0, ob = 0;
+    int nply = 0, gid = -1;
+    if (live) {
+        const Node root = d.nodes[(size_t)g * d.cap_nodes];
+        const Edge* edges = d.edges + (size_t)g * d.cap_edges;
+        const bool pass = root.legal == 0;
+        const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
+        const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
+        const int n = act ? (int)edges[root.edge_base + rank].n : 0;
+        const int n64 = pass ? (int)edges[root.edge_base].n : 0;
+        const int total = wave_sum_i32(n) + n64;
+        // counts / counts.sum() in float32 (node.py:175-177 with temperature 1)
+        const float tot_f = (float)total;
+        float pi = act ? (float)n / tot_f : 0.0f;
+        float pi64 = pass ? (float)n64 / tot_f : 0.0f;
+        // first maximum of the visit counts (np.argmax)
+        const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
+        const unsigned long long eqm = __ballot(act && n == best_n);
+        const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+        const int ply = d.g_ply[g];
+        gid = d.g_id[g];
+        const bool sample = ply < d.temp_threshold;
+        int action;
+        if (forced) {
+            action = forced[g];
+        } else if (!sample) {
+            action = amax;
+        } else {
+            // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
+            const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
+            double c = 0.0;
+            double cdf_lane = 0.0;
+            for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
+                c += (double)__shfl(pi, i);
+                if (i == lane) cdf_lane = c;
+            }
+            const double c64 = c + (double)pi64;
+            const unsigned long long gt = __ballot(cdf_lane / c64 > u);
+            action = gt ? (__ffsll(gt) - 1) : 64;
         }
-        const double c64 = c + (double)pi64;
-        const unsigned long long gt = __ballot(cdf_lane / c64 > u);
-        action = gt ? (__ffsll(gt) - 1) : 64;
-    }
-    if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
-        pi = (lane == amax) ? 1.0f : 0.0f;
-        pi64 = (amax == 64) ? 1.0f : 0.0f;
-    }
-    // record the sample: position bits (state planes are unpacked at compaction) and pi
-    uint64_t sb = d.g_self[g], ob = d.g_opp[g];
-    {
-        const size_t h = (size_t)gid * kMaxPly + ply;
-        float* hp = d.hist_pi + h * 65;
-        hp[lane] = pi;
-        if (lane == 0) {
-            hp[64] = pi64;
-            d.hist_bits[h * 3 + 0] = sb;
-            d.hist_bits[h * 3 + 1] = ob;
-            d.hist_bits[h * 3 + 2] = root.legal;
-            atomicAdd(&d.counters[2], 1ULL);
+        if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
+            pi = (lane == amax) ? 1.0f : 0.0f;
+            pi64 = (amax == 64) ? 1.0f : 0.0f;
+        }
+        // record the sample: position bits (state planes are unpacked at compaction) and pi
+        sb = d.g_self[g];
+        ob = d.g_opp[g];
+        {
+            const size_t h = (size_t)gid * kMaxPly + ply;
+            float* hp = d.hist_pi + h * 65;
+            hp[lane] = pi;
+            if (lane == 0) {
+                hp[64] = pi64;
+                d.hist_bits[h * 3 + 0] = sb;
+                d.hist_bits[h * 3 + 1] = ob;
+                d.hist_bits[h * 3 + 2] = root.legal;
+            }
+        }
+        apply_known(sb, ob, action);  // game.board.make_move(action)
+        nply = ply + 1;
+        over = is_terminal(sb, ob) || nply >= kMaxPly;
+        if (over) {
+            int new_id = -1;
+            if (lane == 0) {
+                d.game_len[gid] = nply;
+                d.game_winner[gid] = winner(sb, ob);  // relative to the side to move at the end (L16)
+                if (refill) {
+                    const int nid = atomicAdd(d.next_game, 1);
+                    if (nid < d.num_games) new_id = nid;
+                }
+            }
+            new_id = __shfl(new_id, 0);
+            if (new_id >= 0) {
+                gid = new_id;
+                nply = 0;
+                sb = kStartSelf;
+                ob = kStartOpp;
+                next_root = true;
+            }
+        } else {
+            next_root = true;
         }
     }
-    apply_known(sb, ob, action);  // game.board.make_move(action)
-    const int nply = ply + 1;
-    const bool over = is_terminal(sb, ob) || nply >= kMaxPly;
-    if (!over) {
-        if (lane == 0) { d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
-        begin_root(d, g, sb, ob, lane);
-        return;
-    }
-    int new_id = -1;
-    if (lane == 0) {
-        d.game_len[gid] = nply;
-        d.game_winner[gid] = winner(sb, ob);  // relative to the side to move at the end (L16)
-        atomicAdd(&d.counters[3], 1ULL);
-        if (refill) {
-            const int nid = atomicAdd(d.next_game, 1);
-            if (nid < d.num_games) new_id = nid;
-        }
-    }
-    new_id = __shfl(new_id, 0);
-    if (new_id >= 0) {
-        if (lane == 0) { d.g_id[g] = new_id; d.g_ply[g] = 0; d.g_self[g] = kStartSelf; d.g_opp[g] = kStartOpp; }
-        begin_root(d, g, kStartSelf, kStartOpp, lane);
+    const int slot = block_alloc_eval(d, bt, next_root, 0, 0, live ? 1 : 0, over ? 1 : 0);
+    if (!live) return;
+    if (next_root) {
+        if (lane == 0) { d.g_id[g] = gid; d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
+        begin_root(d, g, sb, ob, legal_moves(sb, ob), slot, lane);
     } else if (lane == 0) {
         d.g_active[g] = 0;
         d.g_id[g] = -1;
@@ -499,6 +557,8 @@ struct oth_engine {
     float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
 };
 
+static inline int blocks_for(int n_slots) { return (n_slots + 3) / 4; }
+
 template <typename T>
 static int dev_alloc(oth_engine* e, T** p, size_t count) {
     void* q = nullptr;
@@ -509,7 +569,6 @@ static int dev_alloc(oth_engine* e, T** p, size_t count) {
     return OTH_OK;
 }
 
-static inline int blocks_for(int n_slots) { return (n_slots + 3) / 4; }
 
 static int span_begin(oth_engine* e, hipStream_t s, int kind) {
     if (!e->timing) return OTH_OK;
@@ -588,6 +647,21 @@ static int run_search(oth_engine* e, hipStream_t s) {
     return OTH_OK;
 }
 
+// per-block event counters -> engine totals ([4] = network batches is host-side)
+static int read_counters(oth_engine* e, hipStream_t s) {
+    const size_t nb = (size_t)blocks_for(e->d.n_slots);
+    std::vector<unsigned long long> hc(nb * 8);
+    OTH_HIP(hipMemcpyAsync(hc.data(), e->d.counters, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 8; ++i) {
+        if (i == 4) continue;
+        unsigned long long t = 0;
+        for (size_t b = 0; b < nb; ++b) t += hc[b * 8 + i];
+        e->counters[i] = (int64_t)t;
+    }
+    return OTH_OK;
+}
+
 static int ensure_history(oth_engine* e, int num_games) {
     if (num_games <= e->hist_games) return OTH_OK;
     // (re)allocate per-run history; old buffers stay in allocs until destroy (runs rarely grow)
@@ -621,11 +695,8 @@ static int finish_run(oth_engine* e, int num_games, int64_t* n_samples, hipStrea
                            e->d.game_len, e->d.game_winner, e->d_off, num_games, e->out_states, e->out_pis, e->out_zs);
         OTH_HIP(hipGetLastError());
     }
-    unsigned long long hc[8];
-    OTH_HIP(hipMemcpyAsync(hc, e->d.counters, sizeof(hc), hipMemcpyDeviceToHost, s));
-    OTH_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < 8; ++i)
-        if (i != 4) e->counters[i] = (int64_t)hc[i];
+    int rc = read_counters(e, s);
+    if (rc) return rc;
     e->n_samples = total;
     e->run_games = num_games;
     if (n_samples) *n_samples = total;
@@ -636,7 +707,7 @@ static int reset_run(oth_engine* e, int num_games, uint64_t seed, hipStream_t s)
     int r = ensure_history(e, num_games);
     if (r) return r;
     OTH_HIP(hipMemsetAsync(e->d.game_len, 0, sizeof(int32_t) * num_games, s));
-    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8, s));
+    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
     OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
     OTH_HIP(hipMemsetAsync(e->d.n_active, 0, sizeof(int32_t), s));
     e->d.num_games = num_games;
@@ -684,7 +755,7 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     r |= dev_alloc(e, &d.n_eval, 4);
     r |= dev_alloc(e, &d.logp, ((size_t)G + 64) * 65); r |= dev_alloc(e, &d.val, (size_t)G + 64);
     r |= dev_alloc(e, &d.next_game, 4); r |= dev_alloc(e, &d.n_active, 4);
-    r |= dev_alloc(e, &d.counters, 8);
+    r |= dev_alloc(e, &d.counters, (size_t)blocks_for(G) * 8);
     r |= dev_alloc(e, &e->d_total, 2);
     double* st = nullptr;
     r |= dev_alloc(e, &st, (size_t)S + 4);
@@ -725,7 +796,7 @@ int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int3
     OTH_HIP(hipMemcpyAsync(e->d.g_self, sb, sizeof(uint64_t) * n, hipMemcpyDefault, s));
     OTH_HIP(hipMemcpyAsync(e->d.g_opp, ob, sizeof(uint64_t) * n, hipMemcpyDefault, s));
     OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
-    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8, s));
+    OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
     memset(e->counters, 0, sizeof(e->counters));
     spans_reset(e);
     hipLaunchKernelGGL(k_search_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.g_self, e->d.g_opp, n);
@@ -800,10 +871,8 @@ int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* vi
     if (err == hipSuccess) err = hipStreamSynchronize(s);
     (void)hipFree(dpi); (void)hipFree(dpr); (void)hipFree(dv); (void)hipFree(dw);
     OTH_HIP(err);
-    unsigned long long hc[8];
-    OTH_HIP(hipMemcpy(hc, e->d.counters, sizeof(hc), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i)
-        if (i != 4) e->counters[i] = (int64_t)hc[i];
+    int rc = read_counters(e, s);
+    if (rc) return rc;
     return spans_collect(e);
 }
 
