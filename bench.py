@@ -7,8 +7,8 @@ warmup steps, then exactly K timed steps bracketed by barrier + torch.cuda.synch
 ranks; rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch of synthetic input: every rank plays
-`--games` (default 4096 = BASELINE.json configs[1]) complete self-play games from the initial
-position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
+`--waves` x `--games` (default 2 x 4096) complete self-play games through `--games` = 4096 concurrent
+game slots (BASELINE.json configs[1]; finished slots are refilled) from the initial position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
 simulations per move, c_puct 1.0, temperature threshold 15 -- entirely on the device, and (N>1)
 the ranks all-gather the replay tuples over RCCL.  value = games completed by all ranks / time.
 
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games (= games per step) per GPU")
+    ap.add_argument("--waves", type=int, default=2,
+                    help="games per step per GPU = waves x --games, played through --games slots with refill")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
@@ -103,7 +105,7 @@ def main():
 
     def step(i):
         seed = 42 + 1000003 * (i * world + rank)
-        eng.selfplay_run(args.games, seed, add_noise=True)
+        eng.selfplay_run(args.games * args.waves, seed, add_noise=True)
         st, pi, z = eng.selfplay_device_tensors()
         if world > 1:   # the one exchange step: RCCL all-gather of the replay tuples
             st, pi, z, _ = D.all_gather_replay(st, pi, z)
@@ -128,9 +130,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_games = args.games * args.steps * world
+    total_games = args.games * args.waves * args.steps * world
 
     if rank == 0:
+        traffic = None   # HBM-side bytes per k_trunk launch from the committed PMC profile (4096 positions)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_trunk_traffic.json")) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         net_s = kt["net_ms"] * 1e-3
         flops = stats["evals"] * MFLOP_PER_POSITION * 1e6
         achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
@@ -152,7 +160,7 @@ def main():
             "config": {
                 "workload": "8x8, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank"
                             % (args.sims, args.blocks, args.filters, args.games),
-                "games_per_step_per_gpu": args.games, "weights": "seeded random init (torch.manual_seed(42)), eval mode",
+                "games_per_step_per_gpu": args.games * args.waves, "concurrent_games_per_gpu": args.games, "weights": "seeded random init (torch.manual_seed(42)), eval mode",
                 "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
                 "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
                                                             if world > 1 else "single GPU"),
@@ -163,7 +171,7 @@ def main():
             "roofline": {
                 "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                 "launches": kt["net_launches"],
                 "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),
                 "positions_per_launch": round(stats["evals"] / max(1, kt["net_launches"]), 1),
