@@ -23,8 +23,10 @@
 //     lanes of every ds_read_b128 group (all nine taps) and of every ds_write_b64 group then hit 16
 //     different slots.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "net.h"
@@ -46,6 +48,7 @@ constexpr float kActScale = 16.0f;             // 2^4
 
 struct MfmaWeights {
     int blocks = 0;
+    int shape = 32;            // MFMA shape the fragments are packed for: 32 (32x32x16) or 16 (16x16x32)
     uint4* d_w = nullptr;      // fragments: [layer][step 0..71][wave 0..3][plane hi,lo][64 lanes] x 16 B
     uint4* d_stem = nullptr;   // [step 0..1][wave][plane][64 lanes]
     float* d_bias = nullptr;   // [1 + 2*blocks][128], pre-multiplied by kActScale
@@ -59,7 +62,30 @@ struct MfmaArgs {
     const float* inv;
     int n_res_layers;  // 2 * blocks
     HeadParams heads;
+    unsigned long long* dbg;  // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
+
+#ifdef OTH_STAMPS
+// Diagnostic build: s_memtime phase stamps (never compiled into the shipped library).
+__device__ __forceinline__ unsigned long long oth_clk() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define OTH_STAMP(i) { const unsigned long long t1_ = oth_clk(); ph_[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define OTH_STAMP(i)
+#endif
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), which would
+// expose the L2 latency of the weight fragments prefetched across the layer boundary.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -74,8 +100,14 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                                                   const uint64_t* __restrict__ lgl, int64_t n,
                                                   const int32_t* __restrict__ n_valid, float* __restrict__ logp,
                                                   float* __restrict__ vout) {
-    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
-    constexpr int PB = X3 ? 2 : 4;  // weight fragments in flight (k-steps)
+#ifndef OTH_PD_X3
+#define OTH_PD_X3 2
+#endif
+#ifndef OTH_PB_X3
+#define OTH_PB_X3 2
+#endif
+    constexpr int PD = X3 ? OTH_PD_X3 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
+    constexpr int PB = X3 ? OTH_PB_X3 : 4;  // weight fragments in flight (k-steps)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int64_t nv = n;
     if (n_valid) {
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
         const float inv = a.inv[layer];
         const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
         const bool set_res = layer == 0 || add_res;
-        __syncthreads();  // every wave has finished reading the previous activations
+        lds_barrier();  // every wave has finished reading the previous activations
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
             }
         }
         if (last) break;
-        __syncthreads();
+        lds_barrier();
 
         // ---------------- conv `layer+1`: 9 taps x 8 k-steps of 16 input channels, one software pipeline
         // over all 576 (tap, k-step, tile) fragments: fragment q+PD is requested before the MFMAs of q,
@@ -302,6 +334,247 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     }
 }
 
+// =================================================================================================
+// Variant on v_mfma_f32_16x16x32_f16 (same tile, same LDS image, same fp16x3 arithmetic).  Per wave:
+// 2 row blocks of 16 output channels x 16 tiles of 16 cells; one k-step = 32 input channels.
+//   A operand (weights):     lane l holds W[row = l&15][k = 8*(l>>4) + j]
+//   B operand (activations): lane l holds X[k = 8*(l>>4) + j][col = l&15 = cell of the tile]
+//   D: lane l holds column l&15 (cell), rows 4*(l>>4) + reg: 4 consecutive channels -> 8-byte stores
+// =================================================================================================
+using f32x4 = float __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+#define OTH_AFRAGN(AA, HK, q, NTILES) (lds + ((AA)[(q) % (NTILES)] | ((((uint32_t)(((q) / (NTILES)) << 2)) ^ (HK)) << 4)))
+
+template <bool X3, int TP>
+__global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, const uint64_t* __restrict__ sb,
+                                                    const uint64_t* __restrict__ ob,
+                                                    const uint64_t* __restrict__ lgl, int64_t n,
+                                                    const int32_t* __restrict__ n_valid, float* __restrict__ logp,
+                                                    float* __restrict__ vout) {
+    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight (tiles of 16 cells)
+    constexpr int PB = 2;           // weight k-steps (32 channels) in flight
+    constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup
+    constexpr int NQ = 4 * NT;      // (k-step, tile) fragments per tap
+    constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
+    constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int64_t nv = n;
+    if (n_valid) {
+        const int64_t k = *n_valid;
+        nv = k < n ? k : n;
+    }
+    const int64_t pos0 = (int64_t)blockIdx.x * TP;
+    if (pos0 >= nv) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, c16 = lane & 15;
+
+    if (tid < TP * 64) {  // stem input: im2col of the three bit planes, [TP*64 cells][32 k] f16, k = tap*3 + plane
+        const int p = tid >> 6, c = tid & 63, y = c >> 3, x = c & 7;
+        const bool live = pos0 + p < nv;
+        const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
+        _Float16 vals[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+            const int s = ok ? yy * 8 + xx : 0;
+            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
+            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
+            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
+        }
+        half8* dst = (half8*)(lds + SCR_OFF + tid * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = vals[q * 8 + j];
+            dst[q] = t;
+        }
+    }
+    if (tid < 32) ((uint4*)(lds + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    f32x4 acc[NT][2], res[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][rb][i] = 0.f;
+
+    {   // stem conv: one k-step of 32
+        const uint4* wp = a.stem + ((size_t)wave * 4) * 64 + lane;  // [rb0 hi][rb0 lo][rb1 hi][rb1 lo]
+        half8 wh[2], wlo[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            wh[rb] = __builtin_bit_cast(half8, wp[(rb * 2) * 64]);
+            wlo[rb] = __builtin_bit_cast(half8, wp[(rb * 2 + 1) * 64]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const half8 xh = *(const half8*)(lds + SCR_OFF + (t * 16 + c16) * 64 + g4 * 16);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (X3) acc[t][rb] = mfma32(wlo[rb], xh, acc[t][rb]);
+                acc[t][rb] = mfma32(wh[rb], xh, acc[t][rb]);
+            }
+        }
+    }
+
+    const uint32_t keyw = (uint32_t)((c16 & 7) | (((c16 >> 3) & 1) << 3));
+    uint32_t wr_off[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+        wr_off[rb] = (uint32_t)c16 * kCellBytes + ((((uint32_t)(wave * 4 + rb * 2 + (g4 >> 1))) ^ keyw) << 4) +
+                     8u * (uint32_t)(g4 & 1);
+    const int ch0 = wave * 32 + 4 * g4;  // + 16*rb + e
+
+    const int n_layers = 1 + a.n_res_layers;
+    uint4 wq[PB][4];  // weight ring [slot][rb0 hi, rb0 lo, rb1 hi, rb1 lo] of the conv that follows
+#ifdef OTH_STAMPS
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, t0_ = oth_clk(), tstart_ = t0_;
+#endif
+    for (int layer = 0; layer < n_layers; ++layer) {
+        const bool last = layer == n_layers - 1;
+        // bias first, weights after: the first use of b4 then waits with vmcnt(#weight loads), not vmcnt(0)
+        float4 b4[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) b4[rb] = *(const float4*)(a.bias + layer * 128 + ch0 + 16 * rb);
+        const float inv = a.inv[layer];
+        const uint4* wl = a.w + ((size_t)layer * 36 * 4 + wave) * 256 + lane;  // + step*1024 + frag*64
+        if (!last) {  // first weight fragments of conv `layer+1`: their L2 latency hides under the epilogue
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    if (X3 || !(f & 1)) wq[i][f] = wl[(size_t)i * 1024 + f * 64];
+        }
+        // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split
+        const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
+        const bool set_res = layer == 0 || add_res;
+        OTH_STAMP(0)
+        lds_barrier();  // every wave has finished reading the previous activations
+        OTH_STAMP(1)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float vs[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bb = e == 0 ? b4[rb].x : (e == 1 ? b4[rb].y : (e == 2 ? b4[rb].z : b4[rb].w));
+                    float v = fmaf(acc[t][rb][e], inv, bb);
+                    if (add_res) v += res[t][rb][e];
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, 60000.f);  // ReLU + f16 range clamp (x <= 3750)
+                    if (set_res) res[t][rb][e] = v;
+                    acc[t][rb][e] = 0.f;
+                    vs[e] = v;
+                }
+                if (!last) {
+                    half4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
+                    char* dst = lds + (uint32_t)(t * 16) * kCellBytes + wr_off[rb];
+                    *(half4*)dst = hi;
+                    if (X3) {
+                        half4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(vs[e] - (float)hi[e]);
+                        *(half4*)(dst + 256) = lo;
+                    }
+                }
+            }
+        }
+        if (last) break;
+        OTH_STAMP(2)
+        lds_barrier();
+        OTH_STAMP(3)
+
+        // ---------------- conv `layer+1`: 9 taps x 4 k-steps (32 channels) x 16 tiles of 16 cells
+        for (int tap = 0; tap < 9; ++tap) {
+            // lane-constant tap geometry
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int yo = (c16 >> 3) + dy, xs = (c16 & 7) + dx;  // yo relative to the tile's first row
+            const bool xok = xs >= 0 && xs < 8;
+            const uint32_t hk = (uint32_t)(g4 ^ ((xs & 7) | ((yo & 1) << 3)));
+            uint32_t A[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ys = (t & 3) * 2 + yo;
+                const bool ok = xok && ys >= 0 && ys < 8;
+                A[t] = ok ? (uint32_t)((t >> 2) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)ZERO_OFF;
+            }
+            half8 xh[PD + 1], xl[PD + 1];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                xh[q] = *(const half8*)OTH_AFRAGN(A, hk, q, NT);
+                if (X3) xl[q] = *(const half8*)(OTH_AFRAGN(A, hk, q, NT) + 256);
+            }
+            half8 wh[2], wlo[2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + PD < NQ) {
+                    const int slot = (q + PD) % (PD + 1);
+                    xh[slot] = *(const half8*)OTH_AFRAGN(A, hk, q + PD, NT);
+                    if (X3) xl[slot] = *(const half8*)(OTH_AFRAGN(A, hk, q + PD, NT) + 256);
+                }
+                if ((q % NT) == 0) {  // new k-step of 32 channels
+                    const int kk = q / NT, slot = kk % PB;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        wh[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2]);
+                        if (X3) wlo[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2 + 1]);
+                    }
+                    int nstep = tap * 4 + kk + PB;
+                    nstep = nstep < 36 ? nstep : 35;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        if (X3 || !(f & 1)) wq[slot][f] = wl[(size_t)nstep * 1024 + f * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int t = q % NT;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    if (X3) {
+                        acc[t][rb] = mfma32(wh[rb], xl[q % (PD + 1)], acc[t][rb]);
+                        acc[t][rb] = mfma32(wlo[rb], xh[q % (PD + 1)], acc[t][rb]);
+                    }
+                    acc[t][rb] = mfma32(wh[rb], xh[q % (PD + 1)], acc[t][rb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        OTH_STAMP(4)
+    }
+#ifdef OTH_STAMPS
+    if (a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ph_[i];
+        o[5] = oth_clk() - tstart_;
+    }
+#endif
+
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float us = 1.0f / kActScale;
+            const float4 o = make_float4(res[t][rb][0] * us, res[t][rb][1] * us, res[t][rb][2] * us, res[t][rb][3] * us);
+            *(float4*)(lds + (size_t)(t * 16 + c16) * 512 + (size_t)(ch0 + 16 * rb) * 4) = o;
+        }
+    __syncthreads();
+    for (int p = 0; p < TP; ++p) {
+        if (pos0 + p >= nv) break;
+        heads_forward(a.heads, 128, (const float*)(lds + (size_t)p * 64 * 512), 128, (float*)(lds + SCR_OFF),
+                      logp + (pos0 + p) * 65, vout + pos0 + p);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host: pack weights into fragment order
 // ------------------------------------------------------------------------------------------------
@@ -339,6 +612,35 @@ static float pack_conv(const FoldedConv& c, int k_total, std::vector<uint16_t>& 
     return scale;
 }
 
+
+// A fragment of v_mfma_f32_16x16x32_f16: lane l holds W[row = l&15][k = 8*(l>>4) + j].  Stream per layer:
+// [step (32 channels)][wave][rb0 hi, rb0 lo, rb1 hi, rb1 lo][64 lanes] x 16 B.
+static float pack_conv16(const FoldedConv& c, std::vector<uint16_t>& out, size_t base, int steps,
+                         const std::vector<int>& k_map) {
+    float mx = 0.f;
+    for (float x : c.w) mx = fmaxf(mx, fabsf(x));
+    int e = 0;
+    if (mx > 0.f) e = (int)floorf(log2f(16384.0f / mx));
+    if (e > 24) e = 24;
+    if (e < -24) e = -24;
+    const float scale = ldexpf(1.0f, e);
+    for (int s = 0; s < steps; ++s)
+        for (int w = 0; w < 4; ++w)
+            for (int rb = 0; rb < 2; ++rb)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = s * 32 + 8 * (l >> 4) + j, col = w * 32 + rb * 16 + (l & 15);
+                        const int src = k_map[k];
+                        const float v = src < 0 ? 0.f : c.w[(size_t)src * c.cout + col] * scale;
+                        uint16_t hi, lo;
+                        split_f16(v, hi, lo);
+                        const size_t frag = base + ((size_t)(s * 4 + w) * 4 + rb * 2) * 64 * 8;  // in halfs
+                        out[frag + (size_t)l * 8 + j] = hi;
+                        out[frag + 64 * 8 + (size_t)l * 8 + j] = lo;
+                    }
+    return scale;
+}
+
 void mfma_free_weights(oth_net* net) {
     if (!net->mfma) return;
     if (net->mfma->d_w) (void)hipFree(net->mfma->d_w);
@@ -361,17 +663,20 @@ int mfma_pack_weights(oth_net* net, int precision) {
     const size_t layer_halfs = (size_t)72 * 4 * frag_halfs;
     std::vector<uint16_t> w((size_t)L * layer_halfs), stem((size_t)2 * 4 * frag_halfs);
     std::vector<float> bias((size_t)(L + 1) * 128), inv(L + 1);
-    {   // stem: gemm k = tap*3 + plane for k < 27 == index into [tap][cin=3]
-        std::vector<int> km(32, -1);
-        for (int k = 0; k < 27; ++k) km[k] = k;
-        const float sc = pack_conv(hn.stem, 32, stem, 0, 2, km);
+    const char* shp = getenv("OTH_MFMA_SHAPE");
+    mw->shape = (shp && atoi(shp) == 32) ? 32 : 16;  // 16x16x32 is the default (measured faster: DESIGN.md)
+    std::vector<int> km(1152);
+    for (int k = 0; k < 1152; ++k) km[k] = k;  // k = tap*128 + ci, steps ordered (tap, kk)
+    std::vector<int> ks(32, -1);               // stem: gemm k = tap*3 + plane for k < 27
+    for (int k = 0; k < 27; ++k) ks[k] = k;
+    {
+        const float sc = mw->shape == 16 ? pack_conv16(hn.stem, stem, 0, 1, ks) : pack_conv(hn.stem, 32, stem, 0, 2, ks);
         inv[0] = 1.0f / sc;  // accumulator holds (16 x) * (sc w): divide by sc to get 16 * y
         for (int i = 0; i < 128; ++i) bias[i] = hn.stem.bias[i] * kActScale;
     }
-    std::vector<int> km(1152);
-    for (int k = 0; k < 1152; ++k) km[k] = k;  // k = tap*128 + ci, steps ordered (tap, kk)
     for (int l = 0; l < L; ++l) {
-        const float sc = pack_conv(hn.res[l], 1152, w, (size_t)l * layer_halfs, 72, km);
+        const float sc = mw->shape == 16 ? pack_conv16(hn.res[l], w, (size_t)l * layer_halfs, 36, km)
+                                         : pack_conv(hn.res[l], 1152, w, (size_t)l * layer_halfs, 72, km);
         inv[l + 1] = 1.0f / sc;
         for (int i = 0; i < 128; ++i) bias[(size_t)(l + 1) * 128 + i] = hn.res[l].bias[i] * kActScale;
     }
@@ -396,18 +701,52 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     a.inv = net->mfma->d_inv;
     a.n_res_layers = 2 * net->mfma->blocks;
     a.heads = net->heads;
+    a.dbg = nullptr;
+#ifdef OTH_STAMPS
+    const unsigned dbg_grid = (unsigned)((n + 1) / 2);
+    OTH_HIP(hipMalloc(&a.dbg, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
+    OTH_HIP(hipMemset(a.dbg, 0, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
+#endif
     static bool attr_set = false;
+    constexpr int kLds2 = 2 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 2: 74 240 B, two workgroups per CU
     if (!attr_set) {
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((n + kTilePos - 1) / kTilePos);
-    if (net->precision == OTH_PREC_F16X3)
-        hipLaunchKernelGGL(k_trunk<true>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    else
-        hipLaunchKernelGGL(k_trunk<false>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    const bool x3 = net->precision == OTH_PREC_F16X3;
+    const char* tpe = getenv("OTH_TRUNK_TP");
+    const int tp = net->mfma->shape != 16 ? 4 : ((tpe && atoi(tpe) == 4) ? 4 : 2);  // default: two 2-position workgroups per CU
+    const unsigned grid = (unsigned)((n + tp - 1) / tp);
+    if (net->mfma->shape == 16 && tp == 2) {
+        if (x3) hipLaunchKernelGGL((k_trunk16<true, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
+        else hipLaunchKernelGGL((k_trunk16<false, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    } else if (net->mfma->shape == 16) {
+        if (x3) hipLaunchKernelGGL((k_trunk16<true, 4>), dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
+        else hipLaunchKernelGGL((k_trunk16<false, 4>), dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    } else {
+        if (x3) hipLaunchKernelGGL(k_trunk<true>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
+        else hipLaunchKernelGGL(k_trunk<false>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    }
     OTH_HIP(hipGetLastError());
+#ifdef OTH_STAMPS
+    {
+        OTH_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)dbg_grid * 4 * 8);
+        OTH_HIP(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)dbg_grid * 4; ++w)
+            for (int i = 0; i < 6; ++i) s[i] += (double)h[w * 8 + i];
+        const double nw = (double)dbg_grid * 4;
+        fprintf(stderr, "[stamps] per-wave cycles: prefetch %.0f | barrier1 %.0f | epilogue %.0f | barrier2 %.0f | conv %.0f | total %.0f\n",
+                s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw, s[4] / nw, s[5] / nw);
+        (void)hipFree(a.dbg);
+    }
+#endif
     return OTH_OK;
 }
 
