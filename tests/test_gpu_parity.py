@@ -245,6 +245,43 @@ def test_net_large_batch_and_ragged_tail(pkg):
         assert torch.equal(l2, logp[:n]) and torch.equal(v2, v[:n])   # per-row results independent of batch
 
 
+def test_trunk_kernel_variants_agree(pkg):
+    """All builds of the fused trunk (MFMA shape 16x16x32 with 2 or 4 positions per workgroup, shape
+    32x32x16) give the same answer to ~1e-6 and stay within 1e-4 of torch fp32; variants are picked by
+    environment variables read at load/launch time."""
+    import os
+    torch.manual_seed(7)
+    net = pkg.OthelloResNet(6, 128).eval()
+    pos = game_positions(6, 11)[:301]
+    s = np.array([p[0] for p in pos], dtype=U64)
+    o = np.array([p[1] for p in pos], dtype=U64)
+    ds, do = dev_u64(s), dev_u64(o)
+    lg = pkg.DeviceBoards.legal_moves(ds, do)
+    with torch.no_grad():
+        rl, rv = net.cuda()(pkg.DeviceBoards.tensor_input(ds, do))
+    net.cpu()
+    outs = []
+    old = {k: os.environ.get(k) for k in ("OTH_MFMA_SHAPE", "OTH_TRUNK_TP")}
+    try:
+        for shape, tp in (("16", "2"), ("16", "4"), ("32", "4")):
+            os.environ["OTH_MFMA_SHAPE"], os.environ["OTH_TRUNK_TP"] = shape, tp
+            for prec in ("f16x3", "f16"):
+                ev = pkg.HipResNetEvaluator(net, precision=prec)
+                logp, v = ev.forward_bits(ds, do, lg)
+                tol = 1e-4 if prec == "f16x3" else 2e-3   # single f16 pass is NOT parity-grade (DESIGN.md)
+                assert (logp - rl).abs().max().item() < tol and (v - rv).abs().max().item() < tol, (shape, tp, prec)
+                if prec == "f16x3":
+                    outs.append(logp)
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    for x in outs[1:]:
+        assert (x - outs[0]).abs().max().item() < 5e-6
+
+
 def test_net_weight_refresh(pkg):
     """The trainer mutates the model between calls; the evaluator must pick the new weights up."""
     torch.manual_seed(1)
@@ -370,6 +407,21 @@ def test_selfplay_device_rng_properties(pkg):
                for a, b in zip(data, again))
     other = w.execute_episodes(40)
     assert len(other) != len(data) or any(not np.array_equal(a[0], b[0]) for a, b in zip(data, other))
+
+
+def test_selfplay_400_sims_deep_trees(pkg):
+    """BASELINE.json configs[3] shape (400 sims/move, c_puct 1.5, threshold 20) on a small net and few
+    games: exercises the large per-game arenas end to end; replay tuples must be consistent."""
+    torch.manual_seed(9)
+    net = pkg.OthelloResNet(2, 16).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=400, temperature_threshold=20,
+                                   num_parallel_games=8, c_puct=1.5, verbose=False)
+    np.random.seed(1)
+    data = w.execute_episodes(8)
+    st, pi, z, gl = w.engine.selfplay_fetch(len(data))
+    _check_replay_consistency(pkg, st, pi, z, gl, 20, onehot_late=False)
+    c = w.last_stats
+    assert c["simulations"] == 400 * len(data) and c["games"] == 8
 
 
 def test_serial_worker_device_mode_onehot(pkg):
