@@ -345,6 +345,15 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// Chunk swizzle of the 16x16x32 kernels: within a ds_read_b128 lane group the two chunk indices differ in
+// bit 0 and the cells split as {(y even, x lo), (y odd, x hi)} vs {(y even, x hi), (y odd, x lo)} (x lo/hi =
+// the two halves of the 8 shifted columns), so key bit 0 must flip exactly when BOTH y parity and the x half
+// flip: key = y | x[1:0] << 1 | (x[2] ^ y) << 3.  Brute-force bank model (tools/lds_bank_model.py): 4.0
+// cycles per read for all 9 taps (the (x&7)|(y&1)<<3 key of the 32x32x16 kernel gives 6.67 here).
+__device__ __forceinline__ int swz16(int xs, int ys) {
+    const int y = ys & 1, x = xs & 7;
+    return y | ((x & 3) << 1) | ((((x >> 2) & 1) ^ y) << 3);
+}
 #define OTH_AFRAGN(AA, HK, q, NTILES) (lds + ((AA)[(q) % (NTILES)] | ((((uint32_t)(((q) / (NTILES)) << 2)) ^ (HK)) << 4)))
 
 template <bool X3, int TP>
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         }
     }
 
-    const uint32_t keyw = (uint32_t)((c16 & 7) | (((c16 >> 3) & 1) << 3));
+    const uint32_t keyw = (uint32_t)swz16(c16 & 7, c16 >> 3);
     uint32_t wr_off[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int yo = (c16 >> 3) + dy, xs = (c16 & 7) + dx;  // yo relative to the tile's first row
             const bool xok = xs >= 0 && xs < 8;
-            const uint32_t hk = (uint32_t)(g4 ^ ((xs & 7) | ((yo & 1) << 3)));
+            const uint32_t hk = (uint32_t)(g4 ^ swz16(xs, yo));
             uint32_t A[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
