@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--precision", default=None, help="f16x3 (default for 128 filters), f16, f32")
+    ap.add_argument("--eval-cache", type=int, default=0,
+                    help="log2 entries of the opt-in evaluation cache (0 = off; the headline number is measured with it OFF)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     args = ap.parse_args()
@@ -95,7 +97,8 @@ def main():
     torch.manual_seed(42)
     net = pkg.OthelloResNet(args.blocks, args.filters).eval()
     ev = pkg.HipResNetEvaluator(net, precision=args.precision)
-    eng = pkg.SearchEngine(args.games, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev)
+    eng = pkg.SearchEngine(args.games, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev,
+                           eval_cache_log2=args.eval_cache)
     eng.set_timing(True)
 
     def barrier():
@@ -116,7 +119,8 @@ def main():
     barrier()
     t0 = time.time()
     samples = 0
-    stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0}
+    stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0,
+             "cache_hits": 0}
     kt = {"net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0}
     for i in range(args.steps):
         samples = step(args.warmup + i)
@@ -164,6 +168,8 @@ def main():
                 "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
                 "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
                                                             if world > 1 else "single GPU"),
+                "eval_cache": ("off (every position the search reaches is evaluated by the network)" if not args.eval_cache
+                               else "ON: 2^%d entries, %d hits -- NOT the headline configuration" % (args.eval_cache, stats["cache_hits"])),
                 "samples_last_step": samples,
                 "evals_per_game": round(stats["evals"] / max(1, stats["games"]), 1),
                 "plies_per_game": round(stats["plies"] / max(1, stats["games"]), 2),

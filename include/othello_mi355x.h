@@ -117,7 +117,10 @@ typedef struct {
     double dirichlet_epsilon;  /* mcts.py:34 */
     int32_t store_late_onehot; /* 1: SelfPlayWorker semantics (pi stored one-hot after the threshold, L14);
                                   0: ParallelSelfPlayWorker semantics (always the visit distribution, L15) */
-    int32_t reserved;
+    int32_t eval_cache_log2;   /* 0 = off (default).  >0: transposition table of 2^n network results keyed by
+                                  position, reused bit-identically within a run (cleared at every run start);
+                                  skips re-evaluating positions the search has already evaluated (no reference
+                                  counterpart: the reference re-evaluates; outputs are identical) */
 } oth_engine_cfg;
 
 oth_engine *oth_engine_create(const oth_engine_cfg *cfg);
@@ -175,7 +178,7 @@ int oth_selfplay_fetch(oth_engine *e, float *states, float *pis, float *zs, int3
 int oth_selfplay_device_ptrs(oth_engine *e, float **states, float **pis, float **zs, int64_t *n_samples);
 
 /* counters of the last run: [0] network evaluations, [1] simulations, [2] plies, [3] games,
- * [4] network batches launched, [5] terminal-leaf simulations */
+ * [4] network batches launched, [5] terminal-leaf simulations, [6] evaluation-cache hits */
 int oth_engine_counters(oth_engine *e, int64_t out[8]);
 /* timing hook for bench.py: HIP-event time (ms) spent in the network kernel during the last run, and
  * the number of launches; measured on the stream the kernels ran on */

@@ -31,7 +31,7 @@ class EngineCfg(C.Structure):  # oth_engine_cfg
     _fields_ = [("max_games", C.c_int32), ("num_simulations", C.c_int32),
                 ("temperature_threshold", C.c_int32), ("c_puct", C.c_float),
                 ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double),
-                ("store_late_onehot", C.c_int32), ("reserved", C.c_int32)]
+                ("store_late_onehot", C.c_int32), ("eval_cache_log2", C.c_int32)]
 
 
 u64p, f32p, i32p, f64p, i64p = (C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_int32),

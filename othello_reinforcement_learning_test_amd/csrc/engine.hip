@@ -60,8 +60,15 @@ struct Dev {  // device pointers + scalars handed to every kernel by value
     uint64_t* hist_bits;   // [num_games][kMaxPly][3]
     float* hist_pi;        // [num_games][kMaxPly][65]
     int32_t *game_len, *game_winner;
-    unsigned long long* counters;  // [8]
+    unsigned long long* counters;  // [blocks][8]
     uint64_t seed;
+    // optional evaluation cache (transposition table of network outputs), direct-mapped
+    uint64_t* ck;       // [C][2] keys (self, opp); all-ones = empty
+    float* cv;          // [C][66] raw policy (65) + value
+    int32_t* clk;       // [C] claim epoch of the last insert
+    int32_t* ins;       // [n_slots] 1 = this game's pending position was evaluated by the network this step
+    uint32_t cmask;     // C - 1, 0 = cache disabled
+    int32_t cepoch;
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------
@@ -109,12 +116,13 @@ struct BlockTally {
     int base;
 };
 __device__ __forceinline__ int block_alloc_eval(const Dev& d, BlockTally& bt, bool need, int n_sims, int n_term,
-                                                int n_plies, int n_games) {
-    __shared__ int s_cnt[4][4];
+                                                int n_plies, int n_games, int n_hits = 0) {
+    __shared__ int s_cnt[4][5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         bt.need[wave] = need ? 1 : 0;
         s_cnt[wave][0] = n_sims; s_cnt[wave][1] = n_term; s_cnt[wave][2] = n_plies; s_cnt[wave][3] = n_games;
+        s_cnt[wave][4] = n_hits;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -126,11 +134,29 @@ __device__ __forceinline__ int block_alloc_eval(const Dev& d, BlockTally& bt, bo
         c[5] += (unsigned long long)(s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]);
         c[2] += (unsigned long long)(s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]);
         c[3] += (unsigned long long)(s_cnt[0][3] + s_cnt[1][3] + s_cnt[2][3] + s_cnt[3][3]);
+        c[6] += (unsigned long long)(s_cnt[0][4] + s_cnt[1][4] + s_cnt[2][4] + s_cnt[3][4]);
     }
     __syncthreads();
     int slot = bt.base;
     for (int w = 0; w < wave; ++w) slot += bt.need[w];
     return slot;
+}
+
+// Evaluation cache lookup: the network is a pure function of (self, opp), so an earlier result for the
+// same position (previous ply's subtree, a transposition, another game) can be reused bit for bit.
+__device__ __forceinline__ uint32_t cache_slot(const Dev& d, uint64_t sb, uint64_t ob) {
+    uint64_t h = ob + 0x9E3779B97F4A7C15ULL;
+    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    h = (h ^ (h >> 27)) * 0x94D049BB133111EBULL;
+    h = (h ^ (h >> 31)) ^ sb;
+    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    h = (h ^ (h >> 27)) * 0x94D049BB133111EBULL;
+    return (uint32_t)(h ^ (h >> 31)) & d.cmask;
+}
+__device__ __forceinline__ int cache_lookup(const Dev& d, uint64_t sb, uint64_t ob) {
+    if (d.cmask == 0) return -1;
+    const uint32_t cs = cache_slot(d, sb, ob);
+    return (d.ck[2 * (size_t)cs] == sb && d.ck[2 * (size_t)cs + 1] == ob) ? (int)cs : -1;
 }
 
 __device__ __forceinline__ void write_eval(const Dev& d, int slot, uint64_t sb, uint64_t ob, uint64_t lg, int lane) {
@@ -151,7 +177,7 @@ __global__ __launch_bounds__(256) void k_select(Dev d) {
     const bool live = g < d.n_slots && d.g_active[g];
     bool need = false, terminal = false;
     uint64_t sb = 0, ob = 0, lg = 0;
-    int depth = 0;
+    int depth = 0, cached = -1;
     Edge* edges = nullptr;
     uint32_t* path = nullptr;
     if (live) {
@@ -192,15 +218,17 @@ __global__ __launch_bounds__(256) void k_select(Dev d) {
         }
         lg = legal_moves(sb, ob);
         terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
-        need = !terminal;
+        if (!terminal) cached = cache_lookup(d, sb, ob);
+        need = !terminal && cached < 0;
     }
-    const int slot = block_alloc_eval(d, bt, need, live ? 1 : 0, terminal ? 1 : 0, 0, 0);
+    int slot = block_alloc_eval(d, bt, need, live ? 1 : 0, terminal ? 1 : 0, 0, 0, cached >= 0 ? 1 : 0);
     if (!live) return;
+    if (cached >= 0) slot = -(cached + 2);  // negative: read the result from cache entry `cached`
     if (terminal) {  // parallel_self_play.py:133-135: back up float(get_winner()) immediately
         backup_path(edges, lpath, depth, (double)winner(sb, ob), lane, 0);
         if (lane == 0) d.pend[g] = PEND_NONE;
     } else {
-        write_eval(d, slot, sb, ob, lg, lane);
+        if (slot >= 0) write_eval(d, slot, sb, ob, lg, lane);
         for (int i = lane; i < depth; i += 64) path[i] = lpath[i];  // for k_expand (next launch)
         if (lane == 0) {
             d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__
     const int pend = d.pend[g];
     if (pend == PEND_NONE) return;
     const int slot = d.eval_slot[g];
-    const float* pol = policy + (size_t)slot * 65;
+    const float* pol = slot >= 0 ? policy + (size_t)slot * 65 : d.cv + (size_t)(-slot - 2) * 66;
     const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g], legal = d.leaf_legal[g];
     const bool pass = legal == 0;
     float p = pol[lane], p64 = pol[64];
@@ -264,10 +292,35 @@ __global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__
         d.n_nodes[g] = id + 1;
         d.n_edges[g] = base + nch;
         d.pend[g] = PEND_NONE;
+        if (d.cmask) d.ins[g] = slot >= 0 ? 1 : 0;
     }
     if (depth > 0) {
-        const double v = (double)value[slot];  // values[j].item(): float32 -> python float
+        const double v = (double)(slot >= 0 ? value[slot] : pol[65]);  // values[j].item(): float32 -> python float
         backup_path(edges, path, depth, v, lane, id);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __restrict__ policy,
+                                                      const float* __restrict__ value) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= d.n_slots || !d.ins[g]) return;
+    const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g];
+    const int slot = d.eval_slot[g];
+    const uint32_t cs = cache_slot(d, sb, ob);
+    int own = 0;
+    if (lane == 0) {
+        own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
+        d.ins[g] = 0;
+    }
+    if (!__shfl(own, 0)) return;
+    float* dst = d.cv + (size_t)cs * 66;
+    dst[lane] = policy[(size_t)slot * 65 + lane];
+    if (lane == 0) {
+        dst[64] = policy[(size_t)slot * 65 + 64];
+        dst[65] = value[slot];
+        d.ck[2 * (size_t)cs] = sb;
+        d.ck[2 * (size_t)cs + 1] = ob;
     }
 }
 
@@ -290,7 +343,7 @@ __device__ inline double philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1)
 // (re)start the search of slot g from position (sb, ob): empty tree, root written to batch slot `slot`
 __device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uint64_t ob, uint64_t lg, int slot,
                                            int lane) {
-    write_eval(d, slot, sb, ob, lg, lane);
+    if (slot >= 0) write_eval(d, slot, sb, ob, lg, lane);
     if (lane == 0) {
         d.n_nodes[g] = 0;
         d.n_edges[g] = 0;
@@ -308,8 +361,10 @@ __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __r
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live = g < n;
     uint64_t s0 = 0, o0 = 0;
-    if (live) { s0 = sb[g]; o0 = ob[g]; }
-    const int slot = block_alloc_eval(d, bt, live, 0, 0, 0, 0);
+    int cached = -1;
+    if (live) { s0 = sb[g]; o0 = ob[g]; cached = cache_lookup(d, s0, o0); }
+    int slot = block_alloc_eval(d, bt, live && cached < 0, 0, 0, 0, 0, cached >= 0 ? 1 : 0);
+    if (cached >= 0) slot = -(cached + 2);
     if (g >= d.n_slots) return;
     if (!live) {
         if (lane == 0) { d.g_active[g] = 0; d.pend[g] = PEND_NONE; }
@@ -325,7 +380,9 @@ __global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live = g < n_start;
-    const int slot = block_alloc_eval(d, bt, live, 0, 0, 0, 0);
+    const int cached = live ? cache_lookup(d, kStartSelf, kStartOpp) : -1;
+    int slot = block_alloc_eval(d, bt, live && cached < 0, 0, 0, 0, 0, cached >= 0 ? 1 : 0);
+    if (cached >= 0) slot = -(cached + 2);
     if (g >= d.n_slots) return;
     if (!live) {
         if (lane == 0) { d.g_active[g] = 0; d.g_id[g] = -1; d.pend[g] = PEND_NONE; }
@@ -432,8 +489,10 @@ __global__ __launch_bounds__(256) void k_ply(Dev d, const int32_t* __restrict__ 
             next_root = true;
         }
     }
-    const int slot = block_alloc_eval(d, bt, next_root, 0, 0, live ? 1 : 0, over ? 1 : 0);
+    const int cached = next_root ? cache_lookup(d, sb, ob) : -1;
+    int slot = block_alloc_eval(d, bt, next_root && cached < 0, 0, 0, live ? 1 : 0, over ? 1 : 0, cached >= 0 ? 1 : 0);
     if (!live) return;
+    if (cached >= 0) slot = -(cached + 2);
     if (next_root) {
         if (lane == 0) { d.g_id[g] = gid; d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
         begin_root(d, g, sb, ob, legal_moves(sb, ob), slot, lane);
@@ -620,6 +679,20 @@ static int launch_net(oth_engine* e, hipStream_t s) {
 static int launch_expand(oth_engine* e, const float* pol, const float* val, int is_log, hipStream_t s) {
     hipLaunchKernelGGL(k_expand, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, pol, val, is_log);
     OTH_HIP(hipGetLastError());
+    if (e->d.cmask) {  // insert the fresh network results; a separate launch so that no entry is read while rewritten
+        e->d.cepoch += 1;
+        hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, pol, val);
+        OTH_HIP(hipGetLastError());
+    }
+    return OTH_OK;
+}
+static int cache_clear(oth_engine* e, hipStream_t s) {
+    if (!e->d.cmask) return OTH_OK;
+    const size_t C = (size_t)e->d.cmask + 1;
+    OTH_HIP(hipMemsetAsync(e->d.ck, 0xFF, C * 2 * sizeof(uint64_t), s));
+    OTH_HIP(hipMemsetAsync(e->d.clk, 0, C * sizeof(int32_t), s));
+    OTH_HIP(hipMemsetAsync(e->d.ins, 0, (size_t)e->d.n_slots * sizeof(int32_t), s));
+    e->d.cepoch = 0;
     return OTH_OK;
 }
 static int launch_select(oth_engine* e, hipStream_t s) {
@@ -714,7 +787,7 @@ static int reset_run(oth_engine* e, int num_games, uint64_t seed, hipStream_t s)
     e->d.seed = seed;
     memset(e->counters, 0, sizeof(e->counters));
     spans_reset(e);
-    return OTH_OK;
+    return cache_clear(e, s);  // the trainer may have changed the weights since the last run
 }
 
 extern "C" {
@@ -757,6 +830,18 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     r |= dev_alloc(e, &d.next_game, 4); r |= dev_alloc(e, &d.n_active, 4);
     r |= dev_alloc(e, &d.counters, (size_t)blocks_for(G) * 8);
     r |= dev_alloc(e, &e->d_total, 2);
+    r |= dev_alloc(e, &d.ins, G);
+    if (cfg->eval_cache_log2 > 0) {
+        const int lg = cfg->eval_cache_log2 < 10 ? 10 : (cfg->eval_cache_log2 > 26 ? 26 : cfg->eval_cache_log2);
+        const size_t C = (size_t)1 << lg;
+        r |= dev_alloc(e, &d.ck, C * 2);
+        r |= dev_alloc(e, &d.cv, C * 66);
+        r |= dev_alloc(e, &d.clk, C);
+        if (!r) {
+            d.cmask = (uint32_t)(C - 1);
+            if (hipMemset(d.ck, 0xFF, C * 2 * sizeof(uint64_t)) != hipSuccess) r = 1;
+        }
+    }
     double* st = nullptr;
     r |= dev_alloc(e, &st, (size_t)S + 4);
     if (r) { oth_engine_destroy(e); return nullptr; }
@@ -799,6 +884,10 @@ int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int3
     OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
     memset(e->counters, 0, sizeof(e->counters));
     spans_reset(e);
+    {
+        int rc = cache_clear(e, s);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_search_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.g_self, e->d.g_opp, n);
     OTH_HIP(hipGetLastError());
     e->n_roots = n;

@@ -92,13 +92,14 @@ class SearchEngine:
     """Handle over oth_engine: G concurrent game slots, one wavefront per game on the device."""
 
     def __init__(self, max_games, num_simulations, temperature_threshold=15, c_puct=1.0,
-                 dirichlet_alpha=0.3, dirichlet_epsilon=0.25, store_late_onehot=False, evaluator=None):
+                 dirichlet_alpha=0.3, dirichlet_epsilon=0.25, store_late_onehot=False, evaluator=None,
+                 eval_cache_log2=0):
         _lib.require_device()
         self.max_games = int(max_games)
         self.num_simulations = int(num_simulations)
         cfg = _lib.EngineCfg(self.max_games, self.num_simulations, int(temperature_threshold),
                              float(c_puct), float(dirichlet_alpha), float(dirichlet_epsilon),
-                             1 if store_late_onehot else 0, 0)
+                             1 if store_late_onehot else 0, int(eval_cache_log2))
         self._h = _lib.load().oth_engine_create(C.byref(cfg))
         if not self._h:
             raise _lib.OthelloHipError("oth_engine_create: " + _lib.last_error())
@@ -230,8 +231,8 @@ class SearchEngine:
     def counters(self):
         out = (C.c_int64 * 8)()
         _lib.call("oth_engine_counters", self._h, out)
-        keys = ("evals", "simulations", "plies", "games", "net_batches", "terminal_sims")
-        return dict(zip(keys, list(out)[:6]))
+        keys = ("evals", "simulations", "plies", "games", "net_batches", "terminal_sims", "cache_hits")
+        return dict(zip(keys, list(out)[:7]))
 
     def set_timing(self, enable=True):
         _lib.call("oth_engine_set_timing", self._h, 1 if enable else 0)

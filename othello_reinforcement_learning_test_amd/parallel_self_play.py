@@ -64,7 +64,7 @@ class BatchMCTS:
 class ParallelSelfPlayWorker:
     def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
                  num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
-                 rng_mode=None, precision=None, verbose=True):
+                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0):
         self.board_class = board_class
         self.num_simulations = num_simulations
         self.temperature_threshold = temperature_threshold
@@ -78,7 +78,8 @@ class ParallelSelfPlayWorker:
         self.engine = SearchEngine(num_parallel_games, num_simulations,
                                    temperature_threshold=temperature_threshold, c_puct=c_puct,
                                    dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
-                                   store_late_onehot=False, evaluator=self.batch_mcts.evaluator)
+                                   store_late_onehot=False, evaluator=self.batch_mcts.evaluator,
+                                   eval_cache_log2=eval_cache_log2)
         self.last_stats = {}
 
     # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------

@@ -424,6 +424,26 @@ def test_selfplay_400_sims_deep_trees(pkg):
     assert c["simulations"] == 400 * len(data) and c["games"] == 8
 
 
+def test_eval_cache_is_bit_identical(pkg):
+    """Opt-in evaluation cache: same seed => identical replay tuples with the cache on and off (the network
+    is a pure function of the position), with fewer network evaluations."""
+    torch.manual_seed(11)
+    net = pkg.OthelloResNet(2, 16).eval()
+    outs, stats = [], []
+    for lg in (0, 16):
+        w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=20, temperature_threshold=8,
+                                       num_parallel_games=32, verbose=False, eval_cache_log2=lg)
+        np.random.seed(5)
+        outs.append(w.execute_episodes(48))
+        stats.append(dict(w.last_stats))
+    assert len(outs[0]) == len(outs[1])
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert stats[0]["cache_hits"] == 0 and stats[1]["cache_hits"] > 0
+    assert stats[1]["evals"] + stats[1]["cache_hits"] == stats[0]["evals"]
+    assert stats[1]["evals"] < 0.85 * stats[0]["evals"]
+
+
 def test_serial_worker_device_mode_onehot(pkg):
     torch.manual_seed(4)
     net = pkg.OthelloResNet(2, 16).eval()
