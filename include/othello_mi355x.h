@@ -185,6 +185,17 @@ int oth_engine_counters(oth_engine *e, int64_t out[8]);
 int oth_engine_kernel_time(oth_engine *e, double *net_ms, int64_t *net_launches, double *tree_ms, int64_t *tree_launches);
 int oth_engine_set_timing(oth_engine *e, int32_t enable);
 
+/* =============================================================================================
+ * 5. Replay-tuple operations on the device
+ * =========================================================================================== */
+/* 8-fold dihedral augmentation = OthelloBitboard.get_symmetries (bitboard.pyx:338-370) applied to every
+ * sample: out[8*i + k] is variant k of sample i (k = 2j: rot90^j; k = 2j+1: that, then left-right flip);
+ * pi[64] and z are copied.  states [n,3,8,8] -> [8n,3,8,8], pis [n,65] -> [8n,65], zs [n] -> [8n].
+ * all DEVICE.  (The reference's augment_data_with_symmetries, self_play.py:166-212, returns its input
+ * unchanged; this is the transform it describes.) */
+int oth_augment_symmetries(const float *states, const float *pis, const float *zs, int64_t n, float *states_out,
+                           float *pis_out, float *zs_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,10 +20,13 @@ from .mcts import MCTS  # noqa: F401
 from .net import OthelloResNet, create_model  # noqa: F401
 from .parallel_self_play import (BatchMCTS, ParallelSelfPlayWorker,  # noqa: F401
                                  create_parallel_self_play_worker)
+from .replay import (DeviceReplayBuffer, augment_symmetries, augment_training_data,  # noqa: F401
+                     load_checkpoint_model)
 from .self_play import GameStep, SelfPlayWorker, augment_data_with_symmetries  # noqa: F401
 
 __all__ = [
     "OthelloBitboard", "DeviceBoards", "MCTS", "BatchMCTS", "SelfPlayWorker", "ParallelSelfPlayWorker",
     "create_parallel_self_play_worker", "GameStep", "augment_data_with_symmetries", "OthelloResNet",
     "create_model", "HipResNetEvaluator", "SearchEngine", "OthelloHipError", "device_available",
+    "DeviceReplayBuffer", "augment_symmetries", "augment_training_data", "load_checkpoint_model",
 ]

@@ -1,0 +1,64 @@
+// replay_ops.hip -- section 5 of include/othello_mi355x.h: operations on replay tuples that stay on the
+// device between self-play and the trainer.
+#include "common.h"
+
+namespace oth {
+
+// get_symmetries (bitboard.pyx:338-370) for a batch of samples.  Variant k = 2j is rot90^j (numpy.rot90,
+// counter-clockwise) of every plane and of pi[:64].reshape(8,8); k = 2j+1 is that followed by a left-right
+// flip; pi[64] (pass) and z are copied.  Literal transform: plane 2 is the ROTATED legal mask, not the legal
+// moves of the rotated position (the reference's rules are not rotation-invariant, SURVEY 8(f1) caveat).
+// One wave per output sample: 3 planes + pi as 256-B coalesced rows.
+__device__ __forceinline__ int sym_src(int k, int r, int c) {
+    const int j = k >> 1;
+    if (k & 1) c = 7 - c;
+    int sr, sc;
+    switch (j) {
+    case 0: sr = r; sc = c; break;
+    case 1: sr = c; sc = 7 - r; break;
+    case 2: sr = 7 - r; sc = 7 - c; break;
+    default: sr = 7 - c; sc = r; break;
+    }
+    return sr * 8 + sc;
+}
+
+__global__ __launch_bounds__(256) void k_symmetries(const float* __restrict__ st, const float* __restrict__ pi,
+                                                    const float* __restrict__ z, int64_t n, float* __restrict__ st_o,
+                                                    float* __restrict__ pi_o, float* __restrict__ z_o) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t o = w; o < n * 8; o += nw) {
+        const int64_t i = o >> 3;
+        const int k = (int)(o & 7);
+        const int src = sym_src(k, lane >> 3, lane & 7);
+        const float* s = st + i * 192;
+        float* d = st_o + o * 192;
+        d[lane] = s[src];
+        d[64 + lane] = s[64 + src];
+        d[128 + lane] = s[128 + src];
+        pi_o[o * 65 + lane] = pi[i * 65 + src];
+        if (lane == 0) {
+            pi_o[o * 65 + 64] = pi[i * 65 + 64];
+            z_o[o] = z[i];
+        }
+    }
+}
+
+}  // namespace oth
+
+using namespace oth;
+
+extern "C" int oth_augment_symmetries(const float* states, const float* pis, const float* zs, int64_t n,
+                                      float* states_out, float* pis_out, float* zs_out, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(n >= 0 && (n == 0 || (states && pis && zs && states_out && pis_out && zs_out)),
+              "oth_augment_symmetries: null pointer or negative n");
+    if (n == 0) return OTH_OK;
+    int64_t blocks = (n * 8 + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_symmetries, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), states, pis, zs, n,
+                       states_out, pis_out, zs_out);
+    OTH_HIP(hipGetLastError());
+    return OTH_OK;
+}

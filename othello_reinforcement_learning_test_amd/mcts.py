@@ -14,6 +14,25 @@ import numpy as np
 from .engine import HipResNetEvaluator, SearchEngine
 
 
+def best_action_from_policy(policy, legal):
+    """mcts.py:288-296: the legal action with the largest probability, first one on ties."""
+    best = legal[0]
+    for a in legal:
+        if policy[a] > policy[best]:
+            best = a
+    return int(best)
+
+
+def evaluations_from_stats(visits, value_sum, legal):
+    """mcts.py:340-360: int((Q + 1) * 50) clipped to [0, 100] for every legal action, int32 (65,)."""
+    out = np.zeros(65, dtype=np.int32)
+    for a in legal:
+        n = int(visits[a])
+        q = 0.0 if n == 0 else float(value_sum[a]) / n
+        out[a] = max(0, min(100, int((q + 1.0) * 50.0)))
+    return out
+
+
 class MCTS:
     def __init__(self, model, device=None, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
                  precision=None):
@@ -62,21 +81,12 @@ class MCTS:
         if num_simulations < 1:
             return legal[0]
         policy, _ = self.search(board, num_simulations, temperature=0.0, add_dirichlet_noise=False)
-        best = legal[0]
-        for a in legal:
-            if policy[a] > policy[best]:
-                best = a
-        return int(best)
+        return best_action_from_policy(policy, legal)
 
     def get_action_evaluations(self, board, num_simulations):
         """mcts.py:298-362: int((Q+1)*50) clipped to [0,100] per legal action, int32 (65,)."""
-        out = np.zeros(65, dtype=np.int32)
         legal = board.get_legal_moves()
         if num_simulations < 1:
-            return out
+            return np.zeros(65, dtype=np.int32)
         _, visits, wsum, _ = self._search_stats(board, num_simulations, 1.0)
-        for a in legal:
-            n = int(visits[0, a])
-            q = 0.0 if n == 0 else float(wsum[0, a]) / n
-            out[a] = max(0, min(100, int((q + 1.0) * 50.0)))
-        return out
+        return evaluations_from_stats(visits[0], wsum[0], legal)

@@ -1,0 +1,156 @@
+"""Replay-tuple handling next to the hot path.
+
+* ``augment_symmetries``      -- the 8-fold transform of ``OthelloBitboard.get_symmetries``
+  (/root/reference/src/cython/bitboard.pyx:338-370) over whole arrays of tuples on the GPU
+  (C ABI ``oth_augment_symmetries``).  The reference's ``augment_data_with_symmetries``
+  (self_play.py:166-212) returns its input unchanged; this is the transform it describes.
+* ``DeviceReplayBuffer``      -- ``ReplayBuffer`` (/root/reference/src/train/buffer.py:18-136) with the
+  storage on the device: FIFO ring of ``(state, pi, z)`` rows, uniform sampling without replacement,
+  same exceptions and return shapes, so tuples never round-trip through host lists.  Pure torch
+  tensor plumbing (works on CPU tensors too, which is how the CPU tests exercise it).
+* ``load_checkpoint_model``   -- reads a trainer checkpoint (trainer.py:375-384) and rebuilds the
+  network, inferring blocks/filters from the key names as players.py:186-202 does.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def augment_symmetries(states, pis, zs):
+    """CUDA tensors (n,3,8,8), (n,65), (n,) -> (8n,3,8,8), (8n,65), (8n,): out[8*i + k] is symmetry k of
+    sample i, in ``get_symmetries`` order."""
+    import torch
+    _lib.require_device()
+    states, pis, zs = states.contiguous(), pis.contiguous(), zs.contiguous()
+    if not (states.is_cuda and pis.is_cuda and zs.is_cuda):
+        raise ValueError("augment_symmetries expects CUDA tensors")
+    n = int(zs.shape[0])
+    so = torch.empty((8 * n, 3, 8, 8), dtype=torch.float32, device=states.device)
+    po = torch.empty((8 * n, 65), dtype=torch.float32, device=states.device)
+    zo = torch.empty((8 * n,), dtype=torch.float32, device=states.device)
+    _lib.call("oth_augment_symmetries", states.data_ptr(), pis.data_ptr(), zs.data_ptr(), n,
+              so.data_ptr(), po.data_ptr(), zo.data_ptr(), _lib.current_stream())
+    return so, po, zo
+
+
+def augment_training_data(training_data):
+    """List-of-tuples form for a caller that holds the reference's data format: 8x the samples."""
+    import torch
+    if not training_data:
+        return []
+    st = torch.from_numpy(np.stack([d[0] for d in training_data])).cuda()
+    pi = torch.from_numpy(np.stack([d[1] for d in training_data])).cuda()
+    z = torch.tensor([d[2] for d in training_data], dtype=torch.float32).cuda()
+    so, po, zo = (t.cpu().numpy() for t in augment_symmetries(st, pi, z))
+    return [(so[i].copy(), po[i].copy(), float(zo[i])) for i in range(len(zo))]
+
+
+class DeviceReplayBuffer:
+    """buffer.py:18-136 with device-resident storage.
+
+    ``add`` accepts either the reference's list of ``(state, pi, z)`` tuples or a triple of tensors
+    ``(states, pis, zs)`` (e.g. ``SearchEngine.selfplay_device_tensors()``: no host copy).
+    Eviction is FIFO like ``deque(maxlen)`` (buffer.py:33); ``sample`` draws uniformly without
+    replacement like ``random.sample`` (buffer.py:78) and raises ``ValueError`` when the buffer holds fewer
+    than ``batch_size`` items (buffer.py:72-75).
+    """
+
+    def __init__(self, max_size=100000, device="cuda"):
+        import torch
+        self.max_size = int(max_size)
+        self.device = torch.device(device)
+        self.states = torch.zeros((self.max_size, 3, 8, 8), dtype=torch.float32, device=self.device)
+        self.policies = torch.zeros((self.max_size, 65), dtype=torch.float32, device=self.device)
+        self.values = torch.zeros((self.max_size,), dtype=torch.float32, device=self.device)
+        self._head = 0      # next write position
+        self._size = 0
+
+    def __len__(self):
+        return self._size
+
+    def is_ready(self, min_size):  # buffer.py:103
+        return self._size >= min_size
+
+    def clear(self):
+        self._head = 0
+        self._size = 0
+
+    def add(self, training_data):
+        import torch
+        if isinstance(training_data, (list,)):
+            if not training_data:
+                return
+            st = torch.from_numpy(np.stack([d[0] for d in training_data]).astype(np.float32))
+            pi = torch.from_numpy(np.stack([d[1] for d in training_data]).astype(np.float32))
+            z = torch.tensor([float(d[2]) for d in training_data], dtype=torch.float32)
+        else:
+            st, pi, z = training_data
+        st = st.to(self.device, torch.float32).reshape(-1, 3, 8, 8)
+        pi = pi.to(self.device, torch.float32).reshape(-1, 65)
+        z = z.to(self.device, torch.float32).reshape(-1)
+        n = int(z.shape[0])
+        if n >= self.max_size:  # only the newest max_size items survive, oldest first
+            st, pi, z = st[n - self.max_size:], pi[n - self.max_size:], z[n - self.max_size:]
+            self.states.copy_(st); self.policies.copy_(pi); self.values.copy_(z)
+            self._head, self._size = 0, self.max_size
+            return
+        idx = (torch.arange(n, device=self.device) + self._head) % self.max_size
+        self.states[idx] = st
+        self.policies[idx] = pi
+        self.values[idx] = z
+        self._head = (self._head + n) % self.max_size
+        self._size = min(self.max_size, self._size + n)
+
+    def _logical_index(self, k):
+        """Ring position of the k-th oldest item."""
+        start = (self._head - self._size) % self.max_size
+        return (start + k) % self.max_size
+
+    def sample(self, batch_size):
+        """-> (states (B,3,8,8), policies (B,65), values (B,1)) tensors on the buffer's device."""
+        import torch
+        if batch_size > self._size:
+            raise ValueError(f"バッファサイズ ({self._size}) がバッチサイズ ({batch_size}) より小さいです")
+        pick = torch.randperm(self._size, device=self.device)[:batch_size]
+        idx = self._logical_index(pick)
+        return self.states[idx], self.policies[idx], self.values[idx].reshape(-1, 1)
+
+    def ordered(self):
+        """All items oldest-first (for tests / checkpoints)."""
+        import torch
+        idx = self._logical_index(torch.arange(self._size, device=self.device))
+        return self.states[idx], self.policies[idx], self.values[idx]
+
+    def get_statistics(self):  # buffer.py:107-136
+        if self._size == 0:
+            return {"size": 0, "capacity": self.max_size, "usage": 0.0}
+        _, _, v = self.ordered()
+        return {
+            "size": self._size, "capacity": self.max_size, "usage": self._size / self.max_size,
+            "value_mean": float(v.mean()), "value_std": float(v.std(unbiased=False)),
+            "value_min": float(v.min()), "value_max": float(v.max()),
+        }
+
+
+def infer_architecture(state_dict):
+    """(num_blocks, num_filters) from parameter names, as players.py:186-202 does."""
+    blocks = 0
+    for k in state_dict:
+        if k.startswith("res_blocks."):
+            blocks = max(blocks, int(k.split(".")[1]) + 1)
+    filters = int(state_dict["conv_block.conv.weight"].shape[0])
+    return blocks, filters
+
+
+def load_checkpoint_model(path, map_location="cpu"):
+    """Trainer checkpoint (trainer.py:375-384: dict with 'model_state_dict') or a bare state_dict ->
+    ``net.OthelloResNet`` in eval mode.  Loaded with ``weights_only=True`` (nothing from the file executes)."""
+    import torch
+
+    from .net import OthelloResNet
+    obj = torch.load(path, map_location=map_location, weights_only=True)
+    sd = obj["model_state_dict"] if isinstance(obj, dict) and "model_state_dict" in obj else obj
+    blocks, filters = infer_architecture(sd)
+    model = OthelloResNet(blocks, filters).eval()
+    model.load_state_dict(sd)
+    return model

@@ -171,6 +171,22 @@ def test_search_deep_tree_400_sims(pkg, g3):
         assert np.array_equal(visits[i], on) and np.array_equal(wsum[i], ow)
 
 
+def test_best_action_and_evaluations_vs_reference(pkg, g3):
+    """get_best_action / get_action_evaluations (reference mcts.py:257-362) from the device search statistics,
+    against the reference's answers under the stub evaluator."""
+    from othello_reinforcement_learning_test_amd.mcts import best_action_from_policy, evaluations_from_stats
+    table = g3["stub_exp"]
+    fn = lambda s, o, lg: stub_probs_values(s, o, table)   # noqa: E731
+    pos = g3["best_pos"]
+    eng = pkg.SearchEngine(len(pos), 25, c_puct=1.0)
+    pi0, _, _, _ = eng.search_with(pos[:, 0], pos[:, 1], fn, temperature=0.0)
+    _, visits, wsum, _ = eng.search_with(pos[:, 0], pos[:, 1], fn, temperature=1.0)
+    for i, (s, o) in enumerate(pos):
+        legal = ol.legal_list(ol.board(s, o))
+        assert best_action_from_policy(pi0[i], legal) == g3["best_action"][i]
+        assert np.array_equal(evaluations_from_stats(visits[i], wsum[i], legal), g3["evals"][i])
+
+
 def test_search_api_properties(pkg):
     """Restated from the reference's tests/test_mcts.py:158-184,236-256: pi has 65 entries, sums to
     one, is zero off the legal moves; T=0 gives exactly one non-zero entry; best action is legal."""
@@ -466,3 +482,41 @@ def test_trainer_contract_with_replay_buffer_shapes(pkg):
     pols = np.array([d[1] for d in data], dtype=np.float32)
     vals = np.array([d[2] for d in data], dtype=np.float32).reshape(-1, 1)
     assert states.shape[1:] == (3, 8, 8) and pols.shape[1:] == (65,) and vals.shape[1:] == (1,)
+
+
+# =========================================================================================== next rows
+def test_augment_symmetries_device(pkg):
+    """oth_augment_symmetries == OthelloBitboard.get_symmetries (literal transform incl. the legal plane)."""
+    from othello_reinforcement_learning_test_amd.replay import augment_symmetries
+    pos = game_positions(3, 21)[:97]
+    rng = np.random.Generator(np.random.PCG64(2))
+    st = np.stack([ol.tensor(ol.board(s, o)) for s, o, _ in pos])
+    pi = rng.random((len(pos), 65)).astype(np.float32)
+    z = rng.integers(-1, 2, len(pos)).astype(np.float32)
+    so, po, zo = augment_symmetries(torch.from_numpy(st).cuda(), torch.from_numpy(pi).cuda(), torch.from_numpy(z).cuda())
+    so, po, zo = so.cpu().numpy(), po.cpu().numpy(), zo.cpu().numpy()
+    assert so.shape == (8 * len(pos), 3, 8, 8) and po.shape == (8 * len(pos), 65)
+    for i, (s, o, _) in enumerate(pos):
+        es, ep = ol.symmetries(ol.board(s, o), pi[i])
+        assert np.array_equal(so[8 * i:8 * i + 8], es) and np.array_equal(po[8 * i:8 * i + 8], ep)
+        assert np.all(zo[8 * i:8 * i + 8] == z[i])
+
+
+def test_device_replay_buffer_from_engine(pkg):
+    """Self-play tuples go from the engine into the device ring without touching the host."""
+    from othello_reinforcement_learning_test_amd.replay import DeviceReplayBuffer
+    torch.manual_seed(6)
+    net = pkg.OthelloResNet(2, 16).eval()
+    eng = pkg.SearchEngine(16, 5, temperature_threshold=8, evaluator=pkg.HipResNetEvaluator(net))
+    n = eng.selfplay_run(16, seed=3)
+    st, pi, z = eng.selfplay_device_tensors()
+    assert st.is_cuda and st.shape[0] == n
+    buf = DeviceReplayBuffer(max_size=500, device="cuda")
+    buf.add((st, pi, z))
+    assert len(buf) == min(500, n)
+    s, p, v = buf.sample(64)
+    assert s.is_cuda and tuple(s.shape) == (64, 3, 8, 8) and tuple(v.shape) == (64, 1)
+    hs, hp, hz, _ = eng.selfplay_fetch(n)
+    o_s, o_p, o_z = buf.ordered()
+    k = len(buf)
+    assert np.array_equal(o_s.cpu().numpy(), hs[n - k:]) and np.array_equal(o_z.cpu().numpy(), hz[n - k:])
