@@ -101,6 +101,8 @@ def main():
                            eval_cache_log2=args.eval_cache)
     eng.set_timing(True)
 
+    gloo = world > 1 and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -111,9 +113,12 @@ def main():
         eng.selfplay_run(args.games * args.waves, seed, add_noise=True)
         st, pi, z = eng.selfplay_device_tensors()
         if world > 1:   # the one exchange step: RCCL all-gather of the replay tuples
+            if gloo:
+                st, pi, z = st.cpu(), pi.cpu(), z.cpu()
             st, pi, z, _ = D.all_gather_replay(st, pi, z)
         return int(z.shape[0])
 
+    barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -131,7 +136,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_games = args.games * args.waves * args.steps * world

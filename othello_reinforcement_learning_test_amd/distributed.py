@@ -96,15 +96,16 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev:
+        torch.cuda.set_device(local % ndev)   # one GPU per rank on a real node; shared only in rehearsals
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # OTHELLO_DIST_BACKEND=gloo: rehearse the N>1 control flow where RCCL cannot run
+            # (CPU-only container, or several ranks sharing one GPU)
+            backend = os.environ.get("OTHELLO_DIST_BACKEND") or ("nccl" if ndev else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     return rank, world, local
