@@ -298,6 +298,51 @@ def test_trunk_kernel_variants_agree(pkg):
         assert (x - outs[0]).abs().max().item() < 5e-6
 
 
+def test_trunk_on_trained_like_weights(pkg):
+    """fp16x3 trunk with non-trivial BatchNorm statistics, uneven per-channel scales and peaked policies (what a
+    trained checkpoint looks like, unlike the seeded-random init): within 1e-4 of torch fp32 and no noisier
+    against a float64 forward than fp32 arithmetic itself; the single f16 pass is far outside the tolerance."""
+    torch.manual_seed(123)
+    net = pkg.OthelloResNet(6, 128).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 1.2 + 0.1)
+                mod.weight.copy_(torch.rand(mod.num_features, generator=g) * 1.8 + 0.3)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.mul_(torch.exp(torch.randn(mod.weight.shape[0], 1, 1, 1, generator=g) * 0.45))
+        net.policy_head.fc.weight.mul_(2.0)
+    pos = game_positions(8, 31)[:400]
+    s = np.array([p[0] for p in pos], dtype=U64)
+    o = np.array([p[1] for p in pos], dtype=U64)
+    ds, do = dev_u64(s), dev_u64(o)
+    lg = pkg.DeviceBoards.legal_moves(ds, do)
+    x = pkg.DeviceBoards.tensor_input(ds, do)
+    with torch.no_grad():
+        rl, rv = net.cuda()(x)
+        net64 = pkg.OthelloResNet(6, 128).eval().double()
+        net64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()})
+        tl, tv = net64.cuda()(x.double())
+    net.cpu()
+    assert rl.exp().max().item() > 0.3 and tl.min().item() > -60   # peaked but sane policies
+    noise = (rl.double() - tl).abs().max().item()                  # fp32 arithmetic's own distance from float64
+    errs = {}
+    for prec in ("f16x3", "f32", "f16"):
+        ev = pkg.HipResNetEvaluator(net, precision=prec)
+        logp, v = ev.forward_bits(ds, do, lg)
+        errs[prec] = ((logp - rl).abs().max().item(), (v - rv).abs().max().item(),
+                      (logp.double() - tl).abs().max().item())
+    print("trained-like net: torch fp32 vs float64 %.2e; max |dlogp| vs torch fp32: f16x3 %.2e, f32 %.2e, single f16 %.2e"
+          % (noise, errs["f16x3"][0], errs["f32"][0], errs["f16"][0]))
+    for prec in ("f16x3", "f32"):
+        assert errs[prec][0] < 1e-4 and errs[prec][1] < 1e-4, (prec, errs[prec])
+        assert errs[prec][2] < 3 * noise + 1e-6, (prec, errs[prec], noise)
+    assert errs["f16"][0] > 1e-4     # why the single pass is not the default
+
+
 def test_net_weight_refresh(pkg):
     """The trainer mutates the model between calls; the evaluator must pick the new weights up."""
     torch.manual_seed(1)
