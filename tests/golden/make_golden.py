@@ -16,6 +16,7 @@ are stored (fixtures G1..G5).  Files are small (each wel
                    inputs, log-probs, values
   g5_episodes.npz  SelfPlayWorker and ParallelSelfPlayWorker episode streams (2x16 net, 5 sims,
                    seeds 42/43): states, pi, z, actions, and the numpy RNG draws they consumed
+  g6_arena.npz     src/eval Arena results (greedy/random players, seeded) and GreedyPlayer choices
 """
 import hashlib
 import os
@@ -422,12 +423,55 @@ def gen_episodes():
     np.savez_compressed(os.path.join(HERE, "g5_episodes.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G6
+def gen_arena():
+    """Reference Arena + host players (src/eval): deterministic and seeded matches, result fields only."""
+    import random as pyrandom
+
+    from src.eval.arena import Arena
+    from src.eval.players import GreedyPlayer, RandomPlayer
+    out = {}
+    arena = Arena(verbose=False)
+    res = arena.play_matches(GreedyPlayer("G1"), GreedyPlayer("G2"), num_games=4, alternate_colors=True)
+    out["greedy_greedy"] = np.array([[r.winner, r.player1_score, r.player2_score, r.num_moves] for r in res],
+                                    dtype=np.int32)
+    for seed in (1, 2):
+        pyrandom.seed(seed)
+        res = arena.play_matches(RandomPlayer("R"), GreedyPlayer("G"), num_games=12, alternate_colors=True)
+        out["random_greedy_s%d" % seed] = np.array(
+            [[r.winner, r.player1_score, r.player2_score, r.num_moves] for r in res], dtype=np.int32)
+        pyrandom.seed(seed)
+        res = arena.play_matches(GreedyPlayer("G"), RandomPlayer("R"), num_games=6, alternate_colors=False)
+        out["greedy_random_s%d" % seed] = np.array(
+            [[r.winner, r.player1_score, r.player2_score, r.num_moves] for r in res], dtype=np.int32)
+    # greedy move choice on sampled positions
+    rng = np.random.Generator(np.random.PCG64(4))
+    g = GreedyPlayer()
+    pos, act = [], []
+    for _ in range(6):
+        b = bb.OthelloBitboard()
+        while not b.is_terminal():
+            pos.append((b.self_board, b.opp_board, b.move_count))
+            act.append(g.get_action(b))
+            mv = b.get_legal_moves()
+            b.make_move(int(mv[rng.integers(len(mv))]))
+    out["greedy_pos"] = np.array([[p[0], p[1]] for p in pos], dtype=U64)
+    out["greedy_mc"] = np.array([p[2] for p in pos], dtype=np.int32)
+    out["greedy_action"] = np.array(act, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "g6_arena.npz"), **out)
+    print("g6: arena results and %d greedy choices" % len(act))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if "--only-arena" in sys.argv:
+        gen_arena()
+        sys.exit(0)
     rows = gen_rules()
     gen_search(rows)
     gen_net(rows)
     gen_episodes()
+    gen_arena()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-18s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -565,3 +565,19 @@ def test_device_replay_buffer_from_engine(pkg):
     o_s, o_p, o_z = buf.ordered()
     k = len(buf)
     assert np.array_equal(o_s.cpu().numpy(), hs[n - k:]) and np.array_equal(o_z.cpu().numpy(), hz[n - k:])
+
+
+def test_batched_arena_equals_sequential(pkg):
+    """Lock-step batched evaluation (one device search per ply over all boards) gives, against a deterministic
+    opponent, exactly the matches the reference-style sequential Arena plays with MCTSPlayer."""
+    from othello_reinforcement_learning_test_amd.arena import Arena, BatchedArena, GreedyPlayer, MCTSPlayer
+    torch.manual_seed(8)
+    net = pkg.OthelloResNet(2, 16).eval()
+    mp = MCTSPlayer(net, torch.device("cuda"), num_simulations=12, name="AI")
+    seq = Arena(verbose=False).play_matches(mp, GreedyPlayer("G"), num_games=6, alternate_colors=True)
+    bm = pkg.BatchMCTS(net, c_puct=1.0, evaluator=mp.mcts.evaluator)
+    bat = BatchedArena(bm, num_simulations=12).play_matches("AI", GreedyPlayer("G"), num_games=6)
+    for a, b in zip(seq, bat):
+        assert (a.winner, a.player1_score, a.player2_score, a.num_moves) == \
+               (b.winner, b.player1_score, b.player2_score, b.num_moves)
+    assert all(r.num_moves >= 9 for r in seq)
