@@ -183,6 +183,7 @@ def main():
                 "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                "frac_mfma_issue": round(achieved * (3 if prec == "f16x3" else 1) / PEAK_F16_TFLOPS, 4),
                 "launches": kt["net_launches"],
                 "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),
                 "positions_per_launch": round(stats["evals"] / max(1, kt["net_launches"]), 1),

@@ -110,7 +110,7 @@ typedef struct oth_engine oth_engine;
 
 typedef struct {
     int32_t max_games;         /* G: concurrent game slots (num_parallel_games, parallel_self_play.py:232) */
-    int32_t num_simulations;   /* mcts.num_simulations */
+    int32_t num_simulations;   /* mcts.num_simulations (0..4000) */
     int32_t temperature_threshold; /* self_play.temperature_threshold */
     float c_puct;              /* python float -> float32 weak scalar at node.py:116 */
     double dirichlet_alpha;    /* mcts.py:33 */

@@ -614,6 +614,10 @@ struct oth_engine {
     double net_ms = 0, tree_ms = 0;
     int64_t net_launches = 0, tree_launches = 0;
     float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
+    // result scratch (allocated once): pi/prior f32 [G,65], visits i32 [G,65], value sums f64 [G,65], actions i32 [G]
+    float *r_pi = nullptr, *r_prior = nullptr;
+    int32_t *r_visits = nullptr, *r_act = nullptr;
+    double* r_wsum = nullptr;
 };
 
 static inline int blocks_for(int n_slots) { return (n_slots + 3) / 4; }
@@ -797,8 +801,9 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         set_error("oth_engine_create: no gfx950 (MI355X) device available; there is no CPU fallback");
         return nullptr;
     }
-    if (!cfg || cfg->max_games < 1 || cfg->num_simulations < 0 || cfg->num_simulations > 60000) {
-        set_error("oth_engine_create: bad configuration");
+    if (!cfg || cfg->max_games < 1 || cfg->num_simulations < 0 || cfg->num_simulations > 4000) {
+        // the descent path of a simulation is staged in LDS: 4 waves x (S+2) x 4 B must fit 64 KiB
+        set_error("oth_engine_create: need max_games >= 1 and 0 <= num_simulations <= 4000");
         return nullptr;
     }
     oth_engine* e = new oth_engine();
@@ -831,6 +836,9 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     r |= dev_alloc(e, &d.counters, (size_t)blocks_for(G) * 8);
     r |= dev_alloc(e, &e->d_total, 2);
     r |= dev_alloc(e, &d.ins, G);
+    r |= dev_alloc(e, &e->r_pi, (size_t)G * 65); r |= dev_alloc(e, &e->r_prior, (size_t)G * 65);
+    r |= dev_alloc(e, &e->r_visits, (size_t)G * 65); r |= dev_alloc(e, &e->r_wsum, (size_t)G * 65);
+    r |= dev_alloc(e, &e->r_act, G);
     if (cfg->eval_cache_log2 > 0) {
         const int lg = cfg->eval_cache_log2 < 10 ? 10 : (cfg->eval_cache_log2 > 26 ? 26 : cfg->eval_cache_log2);
         const size_t C = (size_t)1 << lg;
@@ -944,22 +952,16 @@ int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* vi
     OTH_CHECK(temperature == 0.0 || temperature == 1.0, "oth_search_results: temperature must be 0 or 1");
     hipStream_t s = as_stream(stream);
     const int n = e->n_roots;
-    float *dpi = nullptr, *dpr = nullptr;
-    int32_t* dv = nullptr;
-    double* dw = nullptr;
-    OTH_HIP(hipMalloc(&dpi, sizeof(float) * 65 * n));
-    OTH_HIP(hipMalloc(&dpr, sizeof(float) * 65 * n));
-    OTH_HIP(hipMalloc(&dv, sizeof(int32_t) * 65 * n));
-    OTH_HIP(hipMalloc(&dw, sizeof(double) * 65 * n));
+    float *dpi = e->r_pi, *dpr = e->r_prior;
+    int32_t* dv = e->r_visits;
+    double* dw = e->r_wsum;
     hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, temperature == 0.0 ? 1 : 0, dpi, dv, dw, dpr);
-    hipError_t err = hipGetLastError();
-    if (err == hipSuccess && pi) err = hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess && visits) err = hipMemcpyAsync(visits, dv, sizeof(int32_t) * 65 * n, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess && wsum) err = hipMemcpyAsync(wsum, dw, sizeof(double) * 65 * n, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess && prior) err = hipMemcpyAsync(prior, dpr, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess) err = hipStreamSynchronize(s);
-    (void)hipFree(dpi); (void)hipFree(dpr); (void)hipFree(dv); (void)hipFree(dw);
-    OTH_HIP(err);
+    OTH_HIP(hipGetLastError());
+    if (pi) OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
+    if (visits) OTH_HIP(hipMemcpyAsync(visits, dv, sizeof(int32_t) * 65 * n, hipMemcpyDeviceToHost, s));
+    if (wsum) OTH_HIP(hipMemcpyAsync(wsum, dw, sizeof(double) * 65 * n, hipMemcpyDeviceToHost, s));
+    if (prior) OTH_HIP(hipMemcpyAsync(prior, dpr, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
     int rc = read_counters(e, s);
     if (rc) return rc;
     return spans_collect(e);
@@ -1024,16 +1026,13 @@ int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream)
     const int n = e->n_roots;
     if (active) OTH_HIP(hipMemcpyAsync(active, e->d.g_active, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     if (pi) {
-        float* dpi = nullptr;
-        OTH_HIP(hipMalloc(&dpi, sizeof(float) * 65 * n));
+        float* dpi = e->r_pi;
         OTH_HIP(hipMemsetAsync(dpi, 0, sizeof(float) * 65 * n, s));
         // finished games keep a stale tree: their rows are garbage by contract (active[i] == 0)
         hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, 0, dpi, (int32_t*)nullptr,
                            (double*)nullptr, (float*)nullptr);
-        hipError_t err = hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s);
-        if (err == hipSuccess) err = hipStreamSynchronize(s);
-        (void)hipFree(dpi);
-        OTH_HIP(err);
+        OTH_HIP(hipGetLastError());
+        OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
     }
     OTH_HIP(hipStreamSynchronize(s));
     return OTH_OK;
@@ -1043,18 +1042,15 @@ int oth_selfplay_apply(oth_engine* e, const int32_t* actions, int32_t* n_unfinis
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->lockstep && actions, "oth_selfplay_apply: bad state or arguments");
     hipStream_t s = as_stream(stream);
-    int32_t* dact = nullptr;
-    OTH_HIP(hipMalloc(&dact, sizeof(int32_t) * e->d.n_slots));
+    int32_t* dact = e->r_act;
     OTH_HIP(hipMemsetAsync(dact, 0, sizeof(int32_t) * e->d.n_slots, s));
     OTH_HIP(hipMemcpyAsync(dact, actions, sizeof(int32_t) * e->n_roots, hipMemcpyDefault, s));
     OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_ply, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, (const int32_t*)dact, 0);
-    hipError_t err = hipGetLastError();
+    OTH_HIP(hipGetLastError());
     int32_t act = 0;
-    if (err == hipSuccess) err = hipMemcpyAsync(&act, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess) err = hipStreamSynchronize(s);
-    (void)hipFree(dact);
-    OTH_HIP(err);
+    OTH_HIP(hipMemcpyAsync(&act, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
     if (n_unfinished) *n_unfinished = act;
     return OTH_OK;
 }
