@@ -581,3 +581,43 @@ def test_batched_arena_equals_sequential(pkg):
         assert (a.winner, a.player1_score, a.player2_score, a.num_moves) == \
                (b.winner, b.player1_score, b.player2_score, b.num_moves)
     assert all(r.num_moves >= 9 for r in seq)
+
+
+def test_training_iterations_end_to_end(pkg):
+    """The loop of trainer.py:165-226 around the engine: self-play -> replay buffer -> SGD steps on the torch
+    module (policy cross-entropy + value MSE as trainer.py:330-364) -> the next self-play call must see the new
+    weights.  Two iterations with the test.yaml-sized network."""
+    from othello_reinforcement_learning_test_amd.replay import DeviceReplayBuffer
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = pkg.OthelloResNet(2, 16).cuda()
+    cfg = {"mcts": {"num_simulations": 5}, "self_play": {"temperature_threshold": 10, "num_parallel_games": 8}}
+    worker = pkg.create_parallel_self_play_worker(cfg, net, torch.device("cuda"), verbose=False)
+    buf = DeviceReplayBuffer(max_size=2000, device="cuda")
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    first_version = None
+    for it in range(2):
+        net.eval()
+        data = worker.execute_episodes(num_episodes=8, add_dirichlet_noise=True)
+        buf.add(data)
+        assert buf.is_ready(16)
+        net.train()
+        for _ in range(3):
+            s, p, v = buf.sample(16)
+            logp, val = net(s)
+            loss = -(p * logp).sum(1).mean() + torch.nn.functional.mse_loss(val, v)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        assert torch.isfinite(loss)
+        ver = worker.batch_mcts.evaluator._version
+        assert first_version is None or ver != first_version   # the evaluator re-read the stepped weights
+        first_version = ver
+    # after training the HIP forward still matches the (updated) torch module
+    net.eval()
+    x = torch.from_numpy(np.stack([ol.tensor(ol.board())])).cuda()
+    worker.batch_mcts.evaluator.refresh()
+    hl, hv = worker.batch_mcts.evaluator.forward_planes(x)
+    with torch.no_grad():
+        tl, tv = net(x)
+    assert (hl - tl).abs().max().item() < 1e-4 and (hv - tv).abs().max().item() < 1e-4
