@@ -335,37 +335,42 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
 }
 
 // =================================================================================================
-// Variant on v_mfma_f32_16x16x32_f16 (same tile, same LDS image, same fp16x3 arithmetic).  Per wave:
-// 2 row blocks of 16 output channels x 16 tiles of 16 cells; one k-step = 32 input channels.
+// Shipped variant: v_mfma_f32_16x16x32_f16, TP positions per workgroup (same fp16x3 arithmetic).
+// Per wave: 2 row blocks of 16 output channels x NT tiles of 16 cells; one k-step = 32 input channels.
 //   A operand (weights):     lane l holds W[row = l&15][k = 8*(l>>4) + j]
 //   B operand (activations): lane l holds X[k = 8*(l>>4) + j][col = l&15 = cell of the tile]
 //   D: lane l holds column l&15 (cell), rows 4*(l>>4) + reg: 4 consecutive channels -> 8-byte stores
+// A tile is BOARD ROW y OF A PAIR OF POSITIONS (lane c16: position c16>>3 of the pair, column c16&7), not two
+// rows of one position: for a tap with dy = -1 (+1) the tile of row 0 (7) reads only padding, so its LDS
+// reads and MFMAs are skipped altogether -- 1/12 of the conv work (zero padding is 16 % of a 3x3 conv on 8x8).
 // =================================================================================================
 using f32x4 = float __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// Chunk swizzle of the 16x16x32 kernels: within a ds_read_b128 lane group the two chunk indices differ in
-// bit 0 and the cells split as {(y even, x lo), (y odd, x hi)} vs {(y even, x hi), (y odd, x lo)} (x lo/hi =
-// the two halves of the 8 shifted columns), so key bit 0 must flip exactly when BOTH y parity and the x half
-// flip: key = y | x[1:0] << 1 | (x[2] ^ y) << 3.  Brute-force bank model (tools/lds_bank_model.py): 4.0
-// cycles per read for all 9 taps (the (x&7)|(y&1)<<3 key of the 32x32x16 kernel gives 6.67 here).
-__device__ __forceinline__ int swz16(int xs, int ys) {
-    const int y = ys & 1, x = xs & 7;
-    return y | ((x & 3) << 1) | ((((x >> 2) & 1) ^ y) << 3);
+// Chunk swizzle: within a ds_read_b128 lane group the two chunk indices differ in bit 0 and the cells split as
+// {(pos 0, x lo), (pos 1, x hi)} vs {(pos 0, x hi), (pos 1, x lo)} (x lo/hi = the two halves of the 8 shifted
+// columns), so key bit 0 must flip exactly when BOTH the position bit and the x half flip:
+// key = p | x[1:0] << 1 | (x[2] ^ p) << 3.  tools/lds_bank_model.py: 4.0 cycles per read for all taps.
+__device__ __forceinline__ int swz16(int xs, int p) {
+    const int x = xs & 7;
+    return (p & 1) | ((x & 3) << 1) | ((((x >> 2) & 1) ^ (p & 1)) << 3);
 }
-#define OTH_AFRAGN(AA, HK, q, NTILES) (lds + ((AA)[(q) % (NTILES)] | ((((uint32_t)(((q) / (NTILES)) << 2)) ^ (HK)) << 4)))
+// i-th tile that has in-board source rows for a tap with row offset DY (tile t <-> board row t & 7)
+template <int DY>
+__device__ __forceinline__ constexpr int valid_tile(int i) {
+    return DY == 0 ? i : (DY < 0 ? i + 1 + (i >= 7 ? 1 : 0) : i + (i >= 7 ? 1 : 0));
+}
 
 template <bool X3, int TP>
 __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, const uint64_t* __restrict__ sb,
-                                                    const uint64_t* __restrict__ ob,
-                                                    const uint64_t* __restrict__ lgl, int64_t n,
-                                                    const int32_t* __restrict__ n_valid, float* __restrict__ logp,
-                                                    float* __restrict__ vout) {
-    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight (tiles of 16 cells)
+                                                                   const uint64_t* __restrict__ ob,
+                                                                   const uint64_t* __restrict__ lgl, int64_t n,
+                                                                   const int32_t* __restrict__ n_valid,
+                                                                   float* __restrict__ logp, float* __restrict__ vout) {
+    constexpr int PD = (X3 || TP == 2) ? 2 : 4;  // activation fragments in flight (tiles of 16 cells)
     constexpr int PB = 2;           // weight k-steps (32 channels) in flight
-    constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup
-    constexpr int NQ = 4 * NT;      // (k-step, tile) fragments per tap
+    constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row)
     constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
     constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -378,6 +383,10 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
     if (pos0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c16 = lane & 15;
+    const int pz = c16 >> 3, cx = c16 & 7;   // position within the pair, board column
+    // LDS cell index of this lane in tile t: ((2*(t>>3) + pz)*64 + (t&7)*8 + cx); lane part and tile part:
+    const uint32_t lane_cell = (uint32_t)(pz * 64 + cx);
+#define OTH_TILE_CELL(t) ((uint32_t)(((t) >> 3) * 128 + ((t) & 7) * 8))
 
     if (tid < TP * 64) {  // stem input: im2col of the three bit planes, [TP*64 cells][32 k] f16, k = tap*3 + plane
         const int p = tid >> 6, c = tid & 63, y = c >> 3, x = c & 7;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const half8 xh = *(const half8*)(lds + SCR_OFF + (t * 16 + c16) * 64 + g4 * 16);
+            const half8 xh = *(const half8*)(lds + SCR_OFF + (OTH_TILE_CELL(t) + lane_cell) * 64 + g4 * 16);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 if (X3) acc[t][rb] = mfma32(wlo[rb], xh, acc[t][rb]);
@@ -434,11 +443,11 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         }
     }
 
-    const uint32_t keyw = (uint32_t)swz16(c16 & 7, c16 >> 3);
+    const uint32_t keyw = (uint32_t)swz16(cx, pz);
     uint32_t wr_off[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
-        wr_off[rb] = (uint32_t)c16 * kCellBytes + ((((uint32_t)(wave * 4 + rb * 2 + (g4 >> 1))) ^ keyw) << 4) +
+        wr_off[rb] = lane_cell * kCellBytes + ((((uint32_t)(wave * 4 + rb * 2 + (g4 >> 1))) ^ keyw) << 4) +
                      8u * (uint32_t)(g4 & 1);
     const int ch0 = wave * 32 + 4 * g4;  // + 16*rb + e
 
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
                     half4 hi;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
-                    char* dst = lds + (uint32_t)(t * 16) * kCellBytes + wr_off[rb];
+                    char* dst = lds + OTH_TILE_CELL(t) * kCellBytes + wr_off[rb];
                     *(half4*)dst = hi;
                     if (X3) {
                         half4 lo;
@@ -503,60 +512,66 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         lds_barrier();
         OTH_STAMP(3)
 
-        // ---------------- conv `layer+1`: 9 taps x 4 k-steps (32 channels) x 16 tiles of 16 cells
-        for (int tap = 0; tap < 9; ++tap) {
-            // lane-constant tap geometry
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int yo = (c16 >> 3) + dy, xs = (c16 & 7) + dx;  // yo relative to the tile's first row
-            const bool xok = xs >= 0 && xs < 8;
-            const uint32_t hk = (uint32_t)(g4 ^ swz16(xs, yo));
-            uint32_t A[NT];
+        // ---------------- conv `layer+1`: 3 row offsets (compile-time) x 3 column offsets x 4 k-steps x tiles
+        auto tap_row = [&](auto DYC) {
+            constexpr int DY = decltype(DYC)::value;
+            constexpr int NTV = DY == 0 ? NT : NT - NT / 8;  // tiles with in-board source rows
+            constexpr int NQ = 4 * NTV;                      // (k-step, tile) fragments of one tap
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int tap = (DY + 1) * 3 + dxi;
+                const int xs = cx + dxi - 1;
+                const bool xok = xs >= 0 && xs < 8;
+                const uint32_t hk = (uint32_t)(g4 ^ swz16(xs, pz));
+                // this lane's source cell of tile t (row (t&7)+DY is in-board for every tile used here)
+                const int src_cell = pz * 64 + DY * 8 + xs;   // + OTH_TILE_CELL(t)
+#define OTH_SRC(i)                                                                                                   \
+    (lds + ((xok ? (uint32_t)((int)OTH_TILE_CELL(valid_tile<DY>((i) % NTV)) + src_cell) * kCellBytes : (uint32_t)ZERO_OFF) | \
+            ((((uint32_t)(((i) / NTV) << 2)) ^ hk) << 4)))
+                half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int ys = (t & 3) * 2 + yo;
-                const bool ok = xok && ys >= 0 && ys < 8;
-                A[t] = ok ? (uint32_t)((t >> 2) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)ZERO_OFF;
-            }
-            half8 xh[PD + 1], xl[PD + 1];
-#pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                xh[q] = *(const half8*)OTH_AFRAGN(A, hk, q, NT);
-                if (X3) xl[q] = *(const half8*)(OTH_AFRAGN(A, hk, q, NT) + 256);
-            }
-            half8 wh[2], wlo[2];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q + PD < NQ) {
-                    const int slot = (q + PD) % (PD + 1);
-                    xh[slot] = *(const half8*)OTH_AFRAGN(A, hk, q + PD, NT);
-                    if (X3) xl[slot] = *(const half8*)(OTH_AFRAGN(A, hk, q + PD, NT) + 256);
+                for (int q = 0; q < PD; ++q) {
+                    xh[q] = *(const half8*)OTH_SRC(q);
+                    if (X3) xl[q] = *(const half8*)(OTH_SRC(q) + 256);
                 }
-                if ((q % NT) == 0) {  // new k-step of 32 channels
-                    const int kk = q / NT, slot = kk % PB;
+                half8 wh[2], wlo[2];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + PD < NQ) {
+                        const int slot = (q + PD) % (PD + 1);
+                        xh[slot] = *(const half8*)OTH_SRC(q + PD);
+                        if (X3) xl[slot] = *(const half8*)(OTH_SRC(q + PD) + 256);
+                    }
+                    if ((q % NTV) == 0) {  // new k-step of 32 channels
+                        const int kk = q / NTV, slot = kk % PB;
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            wh[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2]);
+                            if (X3) wlo[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2 + 1]);
+                        }
+                        int nstep = tap * 4 + kk + PB;
+                        nstep = nstep < 36 ? nstep : 35;
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            if (X3 || !(f & 1)) wq[slot][f] = wl[(size_t)nstep * 1024 + f * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int t = valid_tile<DY>(q % NTV);
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
-                        wh[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2]);
-                        if (X3) wlo[rb] = __builtin_bit_cast(half8, wq[slot][rb * 2 + 1]);
+                        if (X3) {
+                            acc[t][rb] = mfma32(wh[rb], xl[q % (PD + 1)], acc[t][rb]);
+                            acc[t][rb] = mfma32(wlo[rb], xh[q % (PD + 1)], acc[t][rb]);
+                        }
+                        acc[t][rb] = mfma32(wh[rb], xh[q % (PD + 1)], acc[t][rb]);
                     }
-                    int nstep = tap * 4 + kk + PB;
-                    nstep = nstep < 36 ? nstep : 35;
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        if (X3 || !(f & 1)) wq[slot][f] = wl[(size_t)nstep * 1024 + f * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const int t = q % NT;
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    if (X3) {
-                        acc[t][rb] = mfma32(wh[rb], xl[q % (PD + 1)], acc[t][rb]);
-                        acc[t][rb] = mfma32(wlo[rb], xh[q % (PD + 1)], acc[t][rb]);
-                    }
-                    acc[t][rb] = mfma32(wh[rb], xh[q % (PD + 1)], acc[t][rb]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+#undef OTH_SRC
             }
-        }
+        };
+        tap_row(std::integral_constant<int, -1>{});
+        tap_row(std::integral_constant<int, 0>{});
+        tap_row(std::integral_constant<int, 1>{});
         OTH_STAMP(4)
     }
 #ifdef OTH_STAMPS
@@ -574,7 +589,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         for (int rb = 0; rb < 2; ++rb) {
             const float us = 1.0f / kActScale;
             const float4 o = make_float4(res[t][rb][0] * us, res[t][rb][1] * us, res[t][rb][2] * us, res[t][rb][3] * us);
-            *(float4*)(lds + (size_t)(t * 16 + c16) * 512 + (size_t)(ch0 + 16 * rb) * 4) = o;
+            *(float4*)(lds + (size_t)(OTH_TILE_CELL(t) + lane_cell) * 512 + (size_t)(ch0 + 16 * rb) * 4) = o;
         }
     __syncthreads();
     for (int p = 0; p < TP; ++p) {
@@ -582,6 +597,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         heads_forward(a.heads, 128, (const float*)(lds + (size_t)p * 64 * 512), 128, (float*)(lds + SCR_OFF),
                       logp + (pos0 + p) * 65, vout + pos0 + p);
     }
+#undef OTH_TILE_CELL
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -729,7 +745,9 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     }
     const bool x3 = net->precision == OTH_PREC_F16X3;
     const char* tpe = getenv("OTH_TRUNK_TP");
-    const int tp = net->mfma->shape != 16 ? 4 : ((tpe && atoi(tpe) == 4) ? 4 : 2);  // default: two 2-position workgroups per CU
+    // default: two 2-position workgroups per CU for the fp16x3 build; the single-pass build runs 4 positions per
+    // workgroup (its TP = 2 instantiation spills registers)
+    const int tp = net->mfma->shape != 16 ? 4 : (tpe ? (atoi(tpe) == 4 ? 4 : 2) : (x3 ? 2 : 4));
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
     if (net->mfma->shape == 16 && tp == 2) {
         if (x3) hipLaunchKernelGGL((k_trunk16<true, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);

@@ -17,19 +17,20 @@ def key32(xs, ys):
     return (xs & 7) | ((ys & 1) << 3)
 
 
-def key16(xs, ys):
-    y, x = ys & 1, xs & 7
-    return y | ((x & 3) << 1) | ((((x >> 2) & 1) ^ y) << 3)
+def key16(xs, p):
+    p, x = p & 1, xs & 7
+    return p | ((x & 3) << 1) | ((((x >> 2) & 1) ^ p) << 3)
 
 
 def addr16(lane, t, tap, kk, key):
+    """16x16x32 kernel: tile t = board row t&7 of position pair t>>3; lane c16 = (position bit, column)."""
     g4, c16 = lane >> 4, lane & 15
+    pz, cx = c16 >> 3, c16 & 7
     dy, dx = tap // 3 - 1, tap % 3 - 1
-    yo, xs = (c16 >> 3) + dy, (c16 & 7) + dx
-    ys = (t & 3) * 2 + yo
-    ok = 0 <= xs < 8 and 0 <= ys < 8
-    base = ((t >> 2) * 64 + ys * 8 + xs) * 512 if ok else ZERO
-    return base | (((kk << 2) ^ g4 ^ key(xs, yo)) << 4)
+    ys, xs = (t & 7) + dy, cx + dx
+    ok = 0 <= xs < 8 and 0 <= ys < 8       # tiles with ys off the board are skipped by the kernel
+    base = ((2 * (t >> 3) + pz) * 64 + ys * 8 + xs) * 512 if ok else ZERO
+    return base | (((kk << 2) ^ g4 ^ key(xs, pz)) << 4)
 
 
 def addr32(lane, t, tap, kk, key):
@@ -56,7 +57,7 @@ def cycles(addrs):
 
 if __name__ == "__main__":
     for name, fn, nt, nk, key in (("16x16x32, key16 (shipped)", addr16, 16, 4, key16),
-                                  ("16x16x32, key32", addr16, 16, 4, key32),
+                                  ("16x16x32, key32-style (x | p<<3)", addr16, 16, 4, lambda xs, p: (xs & 7) | ((p & 1) << 3)),
                                   ("32x32x16, key32 (shipped)", addr32, 8, 8, key32)):
         c = n = 0
         for tap in range(9):
