@@ -2,26 +2,27 @@
 //
 // Reference: /root/reference/src/model/net.py:182-205 (eval mode; BatchNorm folded at load time).
 //
-// Design (MI355X-first; see DESIGN.md "K3"):
-//   * one 256-thread workgroup (4 waves, one per SIMD, whole 512-register file each) evaluates a
-//     tile of 4 positions = 256 GEMM rows through the stem, all residual blocks and both heads;
-//     the activations NEVER leave the CU: they live in LDS as [cell][hi 128 x f16 | lo 128 x f16]
-//     (512 B per cell, 128 KiB per tile) and every 3x3 tap reads them in place (implicit GEMM, no
-//     im2col copy); out-of-board taps read a zeroed cell.
-//   * wave w owns output channels [32w, 32w+32): its weight operand streams from L2 straight
-//     into registers in MFMA fragment order (host-packed, 1 KiB per wave-load, every byte loaded
-//     exactly once per workgroup and layer); accumulators (8 tiles of 32x32) and the fp32 residual
-//     stay in registers, so there is no barrier inside a layer -- two per layer around the
-//     in-place activation rewrite.
-//   * arithmetic: v_mfma_f32_32x32x16_f16 with both operands split a = a_hi + a_lo (f16 pairs,
-//     ~22 significant bits), three products a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in fp32:
-//     fp32-equivalent results (the 1e-4 parity tolerance leaves no room for a single f16 pass in
-//     general).  OTH_PREC_F16 runs the same kernel with the hi parts only.
-//   * power-of-two scaling of activations (2^4) and of each layer's weights keeps the lo parts in
-//     the normal f16 range; it is undone exactly on the fp32 accumulator.
-//   * LDS bank conflicts: the 16-byte chunk index of a cell is XORed with (x&7)|((y&1)<<3); the 16
-//     lanes of every ds_read_b128 group (all nine taps) and of every ds_write_b64 group then hit 16
-//     different slots.
+// Two builds of the same design live here (DESIGN.md "K3" has the measurements that chose between them):
+//   k_trunk16<X3, TP>  SHIPPED: v_mfma_f32_16x16x32_f16, TP = 2 positions per workgroup, two workgroups per CU,
+//                      tiles = board row of a position pair (padding rows skipped).  Further down in this file.
+//   k_trunk<X3>        first version, kept for A/B (OTH_MFMA_SHAPE=32): v_mfma_f32_32x32x16_f16, 4 positions per
+//                      workgroup, one workgroup per CU.
+//
+// Common design (MI355X-first):
+//   * a workgroup of 4 waves carries its positions through the stem, all residual blocks and both heads in one
+//     launch; the activations NEVER leave the CU: LDS [cell][hi 128 x f16 | lo 128 x f16] (512 B per cell), every
+//     3x3 tap reads them in place (implicit GEMM, no im2col copy); out-of-board taps read a zeroed cell.
+//   * wave w owns output channels [32w, 32w+32): its weight operand streams from L2 straight into registers in
+//     MFMA fragment order (host-packed, 1 KiB per wave-load, every byte loaded exactly once per workgroup and
+//     layer); accumulators and the fp32 residual stay in registers, so there is no barrier inside a layer -- two
+//     LDS-only barriers per layer around the in-place activation rewrite.
+//   * arithmetic: both operands split a = a_hi + a_lo (f16 pairs, ~22 significant bits), three products
+//     a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in fp32: fp32-equivalent results (a single f16 pass is 1e-2
+//     off on trained-like weights).  OTH_PREC_F16 runs the same kernels with the hi parts only.
+//   * power-of-two scaling of activations (2^4, carried through the residual) and of each layer's weights keeps the
+//     lo parts in the normal f16 range; it is undone exactly on the fp32 accumulator.
+//   * LDS bank conflicts: the 16-byte chunk index of a cell is XORed with a key derived from the source cell so that
+//     the 16 lanes of every ds_read_b128 group hit 16 different slots for all nine taps (tools/lds_bank_model.py).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -368,8 +369,14 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
                                                                    const uint64_t* __restrict__ lgl, int64_t n,
                                                                    const int32_t* __restrict__ n_valid,
                                                                    float* __restrict__ logp, float* __restrict__ vout) {
-    constexpr int PD = (X3 || TP == 2) ? 2 : 4;  // activation fragments in flight (tiles of 16 cells)
-    constexpr int PB = 2;           // weight k-steps (32 channels) in flight
+#ifndef OTH16_PD
+#define OTH16_PD 2
+#endif
+#ifndef OTH16_PB
+#define OTH16_PB 2
+#endif
+    constexpr int PD = (X3 || TP == 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
+    constexpr int PB = OTH16_PB;    // weight k-steps (32 channels) in flight
     constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row)
     constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
     constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
