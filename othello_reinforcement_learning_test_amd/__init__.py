@@ -3,6 +3,7 @@
 Drop-in surface (reference module -> here):
   src.cython.bitboard.OthelloBitboard            -> bitboard.OthelloBitboard
   src.mcts.mcts.MCTS                             -> mcts.MCTS
+  src.mcts.node.MCTSNode                         -> node.MCTSNode (host object view; the engine's trees are device arrays)
   src.train.self_play.SelfPlayWorker             -> self_play.SelfPlayWorker
   src.train.parallel_self_play.BatchMCTS         -> parallel_self_play.BatchMCTS
   src.train.parallel_self_play.ParallelSelfPlayWorker / create_parallel_self_play_worker
@@ -21,6 +22,7 @@ from .arena import (Arena, BatchedArena, GreedyPlayer, MatchResult, MCTSPlayer, 
 from .bitboard import DeviceBoards, OthelloBitboard  # noqa: F401
 from .engine import HipResNetEvaluator, SearchEngine  # noqa: F401
 from .mcts import MCTS  # noqa: F401
+from .node import MCTSNode  # noqa: F401
 from .net import OthelloResNet, create_model  # noqa: F401
 from .parallel_self_play import (BatchMCTS, ParallelSelfPlayWorker,  # noqa: F401
                                  create_parallel_self_play_worker)
@@ -29,7 +31,7 @@ from .replay import (DeviceReplayBuffer, augment_symmetries, augment_training_da
 from .self_play import GameStep, SelfPlayWorker, augment_data_with_symmetries  # noqa: F401
 
 __all__ = [
-    "OthelloBitboard", "DeviceBoards", "MCTS", "BatchMCTS", "SelfPlayWorker", "ParallelSelfPlayWorker",
+    "OthelloBitboard", "DeviceBoards", "MCTS", "MCTSNode", "BatchMCTS", "SelfPlayWorker", "ParallelSelfPlayWorker",
     "create_parallel_self_play_worker", "GameStep", "augment_data_with_symmetries", "OthelloResNet",
     "create_model", "HipResNetEvaluator", "SearchEngine", "OthelloHipError", "device_available",
     "DeviceReplayBuffer", "augment_symmetries", "augment_training_data", "load_checkpoint_model",
