@@ -8,7 +8,9 @@ ranks; rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch of synthetic input: every rank plays
 `--waves` x `--games` (default 2 x 4096) complete self-play games through `--games` = 4096 concurrent
-game slots (BASELINE.json configs[1]; finished slots are refilled) from the initial position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
+game slots (BASELINE.json configs[1]; finished slots are refilled; the slots are driven as `--lanes` = 2
+independent groups on two streams so that one group's trunk launches fill the other's tails and tree phases)
+from the initial position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
 simulations per move, c_puct 1.0, temperature threshold 15 -- entirely on the device, and (N>1)
 the ranks all-gather the replay tuples over RCCL.  value = games completed by all ranks / time.
 
@@ -76,6 +78,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--precision", default=None, help="f16x3 (default for 128 filters), f16, f32")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="independent game groups per GPU, each --games/--lanes slots on its own stream and host "
+                         "thread (their kernels overlap: tails and tree phases of one lane are filled by the other)")
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="log2 entries of the opt-in evaluation cache (0 = off; the headline number is measured with it OFF)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,9 +102,15 @@ def main():
     torch.manual_seed(42)
     net = pkg.OthelloResNet(args.blocks, args.filters).eval()
     ev = pkg.HipResNetEvaluator(net, precision=args.precision)
-    eng = pkg.SearchEngine(args.games, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev,
-                           eval_cache_log2=args.eval_cache)
-    eng.set_timing(True)
+    import threading
+    lanes = max(1, args.lanes)
+    assert args.games % lanes == 0
+    engs = [pkg.SearchEngine(args.games // lanes, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev,
+                             eval_cache_log2=args.eval_cache) for _ in range(lanes)]
+    for e_ in engs:
+        e_.set_timing(True)
+    eng = engs[0]
+    streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
 
     gloo = world > 1 and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
 
@@ -108,10 +119,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_lane(k, i):
+        seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
+        if streams[k] is None:
+            engs[k].selfplay_run(args.games * args.waves // lanes, seed, add_noise=True)
+        else:
+            with torch.cuda.stream(streams[k]):
+                engs[k].selfplay_run(args.games * args.waves // lanes, seed, add_noise=True)
+
     def step(i):
-        seed = 42 + 1000003 * (i * world + rank)
-        eng.selfplay_run(args.games * args.waves, seed, add_noise=True)
-        st, pi, z = eng.selfplay_device_tensors()
+        if lanes == 1:
+            run_lane(0, i)
+            st, pi, z = eng.selfplay_device_tensors()
+        else:
+            ths = [threading.Thread(target=run_lane, args=(k, i)) for k in range(lanes)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+            parts = [e_.selfplay_device_tensors() for e_ in engs]
+            st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
         if world > 1:   # the one exchange step: RCCL all-gather of the replay tuples
             if gloo:
                 st, pi, z = st.cpu(), pi.cpu(), z.cpu()
@@ -127,12 +154,26 @@ def main():
     stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0,
              "cache_hits": 0}
     kt = {"net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0}
+    union_ms = 0.0   # time during which at least one trunk launch was running (lanes overlap)
     for i in range(args.steps):
         samples = step(args.warmup + i)
-        for k, v in eng.counters().items():
-            stats[k] += v
-        for k, v in eng.kernel_time().items():
-            kt[k] += v
+        spans = []
+        for e_ in engs:
+            for k, v in e_.counters().items():
+                stats[k] += v
+            for k, v in e_.kernel_time().items():
+                kt[k] += v
+            spans.append(e_.net_spans())
+        sp = np.concatenate(spans)
+        sp = sp[np.argsort(sp[:, 0])]
+        cur_s, cur_e = sp[0]
+        for s_, e2 in sp[1:]:
+            if s_ > cur_e:
+                union_ms += cur_e - cur_s
+                cur_s, cur_e = s_, e2
+            else:
+                cur_e = max(cur_e, e2)
+        union_ms += cur_e - cur_s
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -148,7 +189,9 @@ def main():
                 traffic = json.load(f)["traffic_bytes_per_launch"]
         except Exception:
             pass
-        net_s = kt["net_ms"] * 1e-3
+        # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
+        # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
+        net_s = union_ms * 1e-3
         flops = stats["evals"] * MFLOP_PER_POSITION * 1e6
         achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
         prec = ev.precision
@@ -176,6 +219,7 @@ def main():
                 "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
                 "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
                                                             if world > 1 else "single GPU"),
+                "lanes_per_gpu": lanes,
                 "eval_cache": ("off (every position the search reaches is evaluated by the network)" if not args.eval_cache
                                else "ON: 2^%d entries, %d hits -- NOT the headline configuration" % (args.eval_cache, stats["cache_hits"])),
                 "samples_last_step": samples,
@@ -189,6 +233,9 @@ def main():
                 "frac_mfma_issue": round(achieved * issued / PEAK_F16_TFLOPS, 4),
                 "launches": kt["net_launches"],
                 "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),
+                "busy_ms": round(union_ms, 1), "concurrent_lanes": lanes,
+                "time_basis": "union of the HIP-event intervals of all k_trunk launches (the %d lanes' launches "
+                              "overlap; sum of launch durations = %.0f ms)" % (lanes, kt["net_ms"]),
                 "positions_per_launch": round(stats["evals"] / max(1, kt["net_launches"]), 1),
                 "mfma_flops_issued_per_algorithmic_flop": round(issued, 3),
                 "net_time_share": round(net_s / (dt / max(1, 1)) if dt > 0 else 0.0, 4),

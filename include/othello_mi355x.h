@@ -184,6 +184,10 @@ int oth_engine_counters(oth_engine *e, int64_t out[8]);
  * the number of launches; measured on the stream the kernels ran on */
 int oth_engine_kernel_time(oth_engine *e, double *net_ms, int64_t *net_launches, double *tree_ms, int64_t *tree_launches);
 int oth_engine_set_timing(oth_engine *e, int32_t enable);
+/* (start, end) in ms of every network launch of the last run on ONE process-wide HIP-event time axis, so that the
+ * union of launches that overlap across engines / streams can be formed.  spans: HOST [capacity][2] (may be NULL
+ * to query the count). */
+int oth_engine_net_spans(oth_engine *e, double *spans, int64_t capacity, int64_t *count);
 
 /* =============================================================================================
  * 5. Replay-tuple operations on the device

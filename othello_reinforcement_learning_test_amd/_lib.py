@@ -81,6 +81,7 @@ _SIGS = {
     "oth_engine_counters": (C.c_int, [vp, i64p]),
     "oth_engine_kernel_time": (C.c_int, [vp, f64p, i64p, f64p, i64p]),
     "oth_engine_set_timing": (C.c_int, [vp, C.c_int32]),
+    "oth_engine_net_spans": (C.c_int, [vp, f64p, C.c_int64, i64p]),
     "oth_augment_symmetries": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
 }
 _PLAIN_INT = {"oth_device_available", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}

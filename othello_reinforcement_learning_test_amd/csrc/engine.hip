@@ -611,6 +611,7 @@ struct oth_engine {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<size_t, int>> ev_spans;  // (index of start event, kind 0=net 1=tree)
+    std::vector<double> net_spans;  // (start, end) ms of every network launch of the last run, on the g_ref_event axis
     double net_ms = 0, tree_ms = 0;
     int64_t net_launches = 0, tree_launches = 0;
     float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
@@ -633,6 +634,18 @@ static int dev_alloc(oth_engine* e, T** p, size_t count) {
 }
 
 
+// Process-wide reference event: spans of different engines / streams are reported on one time axis so that a
+// caller can take the union of overlapping network launches (several engines on several streams).
+static hipEvent_t g_ref_event = nullptr;
+static int ensure_ref_event() {
+    if (!g_ref_event) {
+        OTH_HIP(hipEventCreate(&g_ref_event));
+        OTH_HIP(hipEventRecord(g_ref_event, nullptr));
+        OTH_HIP(hipEventSynchronize(g_ref_event));
+    }
+    return OTH_OK;
+}
+
 static int span_begin(oth_engine* e, hipStream_t s, int kind) {
     if (!e->timing) return OTH_OK;
     if (e->ev_used + 2 > e->ev_pool.size()) {
@@ -652,17 +665,25 @@ static int span_end(oth_engine* e, hipStream_t s) {
 }
 static int spans_collect(oth_engine* e) {
     if (!e->timing) return OTH_OK;
+    int rc = ensure_ref_event();
+    if (rc) return rc;
     for (auto& sp : e->ev_spans) {
         float ms = 0;
         OTH_HIP(hipEventElapsedTime(&ms, e->ev_pool[sp.first], e->ev_pool[sp.first + 1]));
-        if (sp.second == 0) { e->net_ms += ms; e->net_launches++; }
-        else { e->tree_ms += ms; e->tree_launches++; }
+        if (sp.second == 0) {
+            e->net_ms += ms; e->net_launches++;
+            float t0 = 0;
+            OTH_HIP(hipEventElapsedTime(&t0, g_ref_event, e->ev_pool[sp.first]));
+            e->net_spans.push_back((double)t0);
+            e->net_spans.push_back((double)t0 + (double)ms);
+        } else { e->tree_ms += ms; e->tree_launches++; }
     }
     e->ev_spans.clear();
     e->ev_used = 0;
     return OTH_OK;
 }
 static void spans_reset(oth_engine* e) {
+    e->net_spans.clear();
     e->net_ms = e->tree_ms = 0;
     e->net_launches = e->tree_launches = 0;
     e->ev_spans.clear();
@@ -1098,6 +1119,18 @@ int oth_engine_counters(oth_engine* e, int64_t out[8]) {
 int oth_engine_set_timing(oth_engine* e, int32_t enable) {
     OTH_CHECK(e, "oth_engine_set_timing: null engine");
     e->timing = enable != 0;
+    if (e->timing) return ensure_ref_event();
+    return OTH_OK;
+}
+
+int oth_engine_net_spans(oth_engine* e, double* spans, int64_t capacity, int64_t* count) {
+    OTH_CHECK(e && count, "oth_engine_net_spans: null argument");
+    const int64_t n = (int64_t)e->net_spans.size() / 2;
+    *count = n;
+    if (spans) {
+        const int64_t m = n < capacity ? n : capacity;
+        for (int64_t i = 0; i < 2 * m; ++i) spans[i] = e->net_spans[(size_t)i];
+    }
     return OTH_OK;
 }
 

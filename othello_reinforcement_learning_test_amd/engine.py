@@ -237,6 +237,16 @@ class SearchEngine:
     def set_timing(self, enable=True):
         _lib.call("oth_engine_set_timing", self._h, 1 if enable else 0)
 
+    def net_spans(self):
+        """(n, 2) array of (start, end) ms of every network launch of the last run on a process-wide time axis
+        (needs set_timing(True))."""
+        n = C.c_int64(0)
+        _lib.call("oth_engine_net_spans", self._h, None, 0, C.byref(n))
+        out = np.zeros((n.value, 2), dtype=np.float64)
+        if n.value:
+            _lib.call("oth_engine_net_spans", self._h, _lib.np_ptr(out, C.c_double), n.value, C.byref(n))
+        return out
+
     def kernel_time(self):
         nm, tm = C.c_double(0), C.c_double(0)
         nl, tl = C.c_int64(0), C.c_int64(0)

@@ -64,7 +64,7 @@ class BatchMCTS:
 class ParallelSelfPlayWorker:
     def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
                  num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
-                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0):
+                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=1):
         self.board_class = board_class
         self.num_simulations = num_simulations
         self.temperature_threshold = temperature_threshold
@@ -80,13 +80,43 @@ class ParallelSelfPlayWorker:
                                    dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
                                    store_late_onehot=False, evaluator=self.batch_mcts.evaluator,
                                    eval_cache_log2=eval_cache_log2)
+        # lanes > 1 (device RNG mode): the slots are split into independent groups, each an engine on its own
+        # stream and host thread; their kernels overlap on the device (one group's network launches fill the
+        # other's tails and tree-search phases: +4 % at 4096 slots).  Results are concatenated lane by lane.
+        self.lanes = max(1, int(lanes))
+        self._lane_engines = [self.engine]
+        if self.lanes > 1:
+            per = max(1, num_parallel_games // self.lanes)
+            self._lane_engines = [SearchEngine(per, num_simulations, temperature_threshold=temperature_threshold,
+                                               c_puct=c_puct, dirichlet_alpha=dirichlet_alpha,
+                                               dirichlet_epsilon=dirichlet_epsilon, store_late_onehot=False,
+                                               evaluator=self.batch_mcts.evaluator, eval_cache_log2=eval_cache_log2)
+                                  for _ in range(self.lanes)]
         self.last_stats = {}
 
     # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------
     def _run_device(self, num_episodes, add_dirichlet_noise):
         seed = int(np.random.randint(0, 2**62))
-        n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
-        return self.engine.selfplay_fetch(n)[:3]
+        if self.lanes == 1 or num_episodes < 2 * self.lanes:
+            n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
+            return self.engine.selfplay_fetch(n)[:3]
+        import threading
+
+        import torch
+        shares = [num_episodes // self.lanes + (1 if k < num_episodes % self.lanes else 0) for k in range(self.lanes)]
+        out = [None] * self.lanes
+
+        def run(k):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = self._lane_engines[k]
+                n = eng.selfplay_run(shares[k], seed + 7919 * (k + 1), add_dirichlet_noise)
+                out[k] = eng.selfplay_fetch(n)[:3]
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(self.lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
 
     # ---- numpy RNG: the reference's lock-step batches, draws in the reference's order --------
     def _execute_batch_numpy(self, batch_size, add_dirichlet_noise):
@@ -139,9 +169,12 @@ class ParallelSelfPlayWorker:
                 data.extend(tuples_from_arrays(states, pis, zs))
                 done += bs
         dt = time.time() - t0
+        counters = {}
+        for eng in (self._lane_engines if self.lanes > 1 and self.rng_mode == "device" else [self.engine]):
+            for k, v in eng.counters().items():
+                counters[k] = counters.get(k, 0) + v
         self.last_stats = {"games": num_episodes, "samples": len(data), "seconds": dt,
-                           "games_per_s": num_episodes / dt if dt > 0 else float("inf"),
-                           **self.engine.counters()}
+                           "games_per_s": num_episodes / dt if dt > 0 else float("inf"), **counters}
         if self.verbose:
             print("  Self-Play: %d/%d games | %s samples | %.1fs (%.2f games/s)" %
                   (num_episodes, num_episodes, format(len(data), ","), dt, self.last_stats["games_per_s"]))

@@ -649,3 +649,42 @@ def test_empty_and_tiny_inputs(pkg):
     so, po, zo = augment_symmetries(torch.empty(0, 3, 8, 8, device="cuda"), torch.empty(0, 65, device="cuda"),
                                     torch.empty(0, device="cuda"))
     assert so.shape == (0, 3, 8, 8) and zo.numel() == 0
+
+
+def test_lanes_overlap_mode(pkg):
+    """lanes=2: two engines on two streams/threads; tuples stay consistent and the counters add up."""
+    torch.manual_seed(12)
+    net = pkg.OthelloResNet(2, 16).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=6, temperature_threshold=8,
+                                   num_parallel_games=16, verbose=False, lanes=2)
+    np.random.seed(3)
+    data = w.execute_episodes(30)
+    st = np.stack([d[0] for d in data]); pi = np.stack([d[1] for d in data])
+    z = np.array([d[2] for d in data], dtype=np.float32)
+    # recover the game lengths from the initial-position markers (every game starts from the start position)
+    start = ol.tensor(ol.board())
+    firsts = [i for i in range(len(st)) if np.array_equal(st[i], start) and (i == 0 or True)]
+    c = w.last_stats
+    assert c["games"] == 30 and c["plies"] == len(data) and c["simulations"] == 6 * len(data)
+    gl = []
+    i = 0
+    while i < len(st):   # walk game by game with the oracle
+        b = ol.board(); n = 0
+        while i + n < len(st) and np.array_equal(st[i + n], ol.tensor(b)):
+            nxt = None
+            if i + n + 1 < len(st):
+                for a in ol.legal_list(b):
+                    if pi[i + n][a] > 0:
+                        cb = ol.board(b.self_board, b.opp_board, b.move_count)
+                        ol.lib().orc_make_move(cb, a)
+                        if np.array_equal(ol.tensor(cb), st[i + n + 1]):
+                            nxt = cb
+                            break
+            n += 1
+            if nxt is None:
+                break
+            b = nxt
+        gl.append(n)
+        i += n
+    assert len(gl) == 30 and sum(gl) == len(data)
+    _check_replay_consistency(pkg, st, pi, z, np.array(gl), 8, onehot_late=False)
