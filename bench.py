@@ -30,6 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
 
 MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
@@ -110,16 +111,22 @@ def main():
     for e_ in engs:
         e_.set_timing(True)
     eng = engs[0]
-    streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
+    streams = [torch.cuda.Stream(device=torch.cuda.current_device()) for _ in range(lanes)] if lanes > 1 else [None]
 
     gloo = world > 1 and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
 
+    dev = torch.cuda.current_device()
+
     def barrier():
         if world > 1:
-            dist.barrier()
+            if gloo:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev])
         torch.cuda.synchronize()
 
     def run_lane(k, i):
+        torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
         seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
         if streams[k] is None:
             engs[k].selfplay_run(args.games * args.waves // lanes, seed, add_noise=True)
@@ -230,6 +237,8 @@ def main():
                 "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                "traffic_basis": "PMC FETCH_SIZE/WRITE_SIZE of a full launch of 4096 positions "
+                                 "(profiles/r01_trunk_traffic.json); algorithmic bytes of that launch: 1.18 MB",
                 "frac_mfma_issue": round(achieved * issued / PEAK_F16_TFLOPS, 4),
                 "launches": kt["net_launches"],
                 "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),

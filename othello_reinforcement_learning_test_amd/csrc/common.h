@@ -39,6 +39,24 @@ bool device_ok();  // a gfx950 device is present and usable
         }                                \
     } while (0)
 
+// The HIP current device is per host thread and new threads start on device 0: every entry point that works on an
+// object (engine, net) rebinds the calling thread to the device the object lives on; the stateless batch calls bind
+// to the device that owns their first device pointer.  One process per GPU is the deployment, but a worker thread
+// of rank r must not silently run on GPU 0.
+int bind_device(int dev);
+int bind_pointer_device(const void* p);
+int current_device();
+#define OTH_BIND(dev)                    \
+    do {                                 \
+        int _r = oth::bind_device(dev);  \
+        if (_r) return _r;               \
+    } while (0)
+#define OTH_BIND_PTR(p)                          \
+    do {                                         \
+        int _r = oth::bind_pointer_device(p);    \
+        if (_r) return _r;                       \
+    } while (0)
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace oth

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -602,6 +603,7 @@ struct oth_engine {
     int64_t out_cap = 0, n_samples = 0;
     int64_t* d_off = nullptr;
     int64_t* d_total = nullptr;
+    int device = 0;   // HIP device of every allocation of this engine
     int32_t n_roots = 0;
     int32_t run_games = 0;
     bool lockstep = false;
@@ -611,7 +613,7 @@ struct oth_engine {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<size_t, int>> ev_spans;  // (index of start event, kind 0=net 1=tree)
-    std::vector<double> net_spans;  // (start, end) ms of every network launch of the last run, on the g_ref_event axis
+    std::vector<double> net_spans;  // (start, end) ms of every network launch of the last run, on the device's reference-event axis
     double net_ms = 0, tree_ms = 0;
     int64_t net_launches = 0, tree_launches = 0;
     float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
@@ -636,13 +638,17 @@ static int dev_alloc(oth_engine* e, T** p, size_t count) {
 
 // Process-wide reference event: spans of different engines / streams are reported on one time axis so that a
 // caller can take the union of overlapping network launches (several engines on several streams).
-static hipEvent_t g_ref_event = nullptr;
-static int ensure_ref_event() {
-    if (!g_ref_event) {
-        OTH_HIP(hipEventCreate(&g_ref_event));
-        OTH_HIP(hipEventRecord(g_ref_event, nullptr));
-        OTH_HIP(hipEventSynchronize(g_ref_event));
+static hipEvent_t g_ref_events[64] = {};   // one per device; created on first use under g_ref_mu
+static std::mutex g_ref_mu;
+static int ensure_ref_event(int dev, hipEvent_t* out) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    hipEvent_t& ev = g_ref_events[dev & 63];
+    if (!ev) {
+        OTH_HIP(hipEventCreate(&ev));
+        OTH_HIP(hipEventRecord(ev, nullptr));
+        OTH_HIP(hipEventSynchronize(ev));
     }
+    if (out) *out = ev;
     return OTH_OK;
 }
 
@@ -665,7 +671,8 @@ static int span_end(oth_engine* e, hipStream_t s) {
 }
 static int spans_collect(oth_engine* e) {
     if (!e->timing) return OTH_OK;
-    int rc = ensure_ref_event();
+    hipEvent_t ref = nullptr;
+    int rc = ensure_ref_event(e->device, &ref);
     if (rc) return rc;
     for (auto& sp : e->ev_spans) {
         float ms = 0;
@@ -673,7 +680,7 @@ static int spans_collect(oth_engine* e) {
         if (sp.second == 0) {
             e->net_ms += ms; e->net_launches++;
             float t0 = 0;
-            OTH_HIP(hipEventElapsedTime(&t0, g_ref_event, e->ev_pool[sp.first]));
+            OTH_HIP(hipEventElapsedTime(&t0, ref, e->ev_pool[sp.first]));
             e->net_spans.push_back((double)t0);
             e->net_spans.push_back((double)t0 + (double)ms);
         } else { e->tree_ms += ms; e->tree_launches++; }
@@ -828,6 +835,7 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         return nullptr;
     }
     oth_engine* e = new oth_engine();
+    e->device = current_device();
     e->cfg = *cfg;
     Dev& d = e->d;
     const int G = cfg->max_games, S = cfg->num_simulations;
@@ -888,6 +896,7 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
 
 void oth_engine_destroy(oth_engine* e) {
     if (!e) return;
+    (void)bind_device(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -905,6 +914,7 @@ int oth_engine_set_net(oth_engine* e, oth_net* net) {
 int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int32_t n, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && sb && ob && n >= 1 && n <= e->d.n_slots, "oth_search_begin: need 1 <= n <= max_games roots");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     // the roots are uploaded straight into the game-position arrays; k_search_begin reads them there
     OTH_HIP(hipMemcpyAsync(e->d.g_self, sb, sizeof(uint64_t) * n, hipMemcpyDefault, s));
@@ -926,12 +936,14 @@ int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int3
 int oth_search_select(oth_engine* e, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->n_roots > 0, "oth_search_select: call oth_search_begin first");
+    OTH_BIND(e->device);
     return launch_select(e, as_stream(stream));
 }
 
 int oth_search_leaves(oth_engine* e, int32_t* count, uint64_t* sb, uint64_t* ob, uint64_t* lg, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && count, "oth_search_leaves: null argument");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int32_t n = 0;
     OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -949,6 +961,7 @@ int oth_search_leaves(oth_engine* e, int32_t* count, uint64_t* sb, uint64_t* ob,
 int oth_search_expand(oth_engine* e, const float* policy, const float* value, int32_t is_log, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && policy && value, "oth_search_expand: null argument");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int32_t n = 0;
     OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -963,6 +976,7 @@ int oth_search_expand(oth_engine* e, const float* policy, const float* value, in
 int oth_search_run(oth_engine* e, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->n_roots > 0, "oth_search_run: call oth_search_begin first");
+    OTH_BIND(e->device);
     return run_search(e, as_stream(stream));
 }
 
@@ -970,6 +984,7 @@ int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* vi
                        void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->n_roots > 0, "oth_search_results: no search in progress");
+    OTH_BIND(e->device);
     OTH_CHECK(temperature == 0.0 || temperature == 1.0, "oth_search_results: temperature must be 0 or 1");
     hipStream_t s = as_stream(stream);
     const int n = e->n_roots;
@@ -994,6 +1009,7 @@ int oth_selfplay_run(oth_engine* e, int32_t num_games, uint64_t seed, int32_t ad
     OTH_NEED_DEVICE();
     (void)add_noise;  // no observable effect on this search: see the header comment
     OTH_CHECK(e && num_games >= 1, "oth_selfplay_run: bad arguments");
+    OTH_BIND(e->device);
     OTH_CHECK(e->net, "oth_selfplay_run: no network set");
     hipStream_t s = as_stream(stream);
     int r = reset_run(e, num_games, seed, s);
@@ -1027,6 +1043,7 @@ int oth_selfplay_run(oth_engine* e, int32_t num_games, uint64_t seed, int32_t ad
 int oth_selfplay_begin(oth_engine* e, int32_t n, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && n >= 1 && n <= e->d.n_slots, "oth_selfplay_begin: need 1 <= n <= max_games");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int r = reset_run(e, n, 0, s);
     if (r) return r;
@@ -1041,6 +1058,7 @@ int oth_selfplay_begin(oth_engine* e, int32_t n, void* stream) {
 int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->lockstep, "oth_selfplay_search: call oth_selfplay_begin first");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int r = run_search(e, s);
     if (r) return r;
@@ -1062,6 +1080,7 @@ int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream)
 int oth_selfplay_apply(oth_engine* e, const int32_t* actions, int32_t* n_unfinished, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->lockstep && actions, "oth_selfplay_apply: bad state or arguments");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int32_t* dact = e->r_act;
     OTH_HIP(hipMemsetAsync(dact, 0, sizeof(int32_t) * e->d.n_slots, s));
@@ -1079,6 +1098,7 @@ int oth_selfplay_apply(oth_engine* e, const int32_t* actions, int32_t* n_unfinis
 int oth_selfplay_end(oth_engine* e, int64_t* n_samples, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->lockstep, "oth_selfplay_end: no lock-step run in progress");
+    OTH_BIND(e->device);
     e->lockstep = false;
     const int n = e->n_roots;
     e->n_roots = 0;
@@ -1088,6 +1108,7 @@ int oth_selfplay_end(oth_engine* e, int64_t* n_samples, void* stream) {
 int oth_selfplay_fetch(oth_engine* e, float* states, float* pis, float* zs, int32_t* game_len, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e, "oth_selfplay_fetch: null engine");
+    OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     const int64_t n = e->n_samples;
     if (n > 0) {
@@ -1119,7 +1140,10 @@ int oth_engine_counters(oth_engine* e, int64_t out[8]) {
 int oth_engine_set_timing(oth_engine* e, int32_t enable) {
     OTH_CHECK(e, "oth_engine_set_timing: null engine");
     e->timing = enable != 0;
-    if (e->timing) return ensure_ref_event();
+    if (e->timing) {
+        OTH_BIND(e->device);
+        return ensure_ref_event(e->device, nullptr);
+    }
     return OTH_OK;
 }
 

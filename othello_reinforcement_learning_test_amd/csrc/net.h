@@ -45,6 +45,7 @@ struct MfmaWeights;  // net_mfma.hip
 }  // namespace oth
 
 struct oth_net {
+    int device = 0;      // HIP device the weights live on (the creating thread's current device)
     int blocks = 0, filters = 0;
     int precision = -1;  // OTH_PREC_*; -1 = no weights loaded
     oth::HostNet host;

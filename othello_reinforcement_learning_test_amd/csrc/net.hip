@@ -190,6 +190,7 @@ oth_net* oth_net_create(int num_blocks, int num_filters, int board_size) {
         return nullptr;
     }
     oth_net* n = new oth_net();
+    n->device = current_device();
     n->blocks = num_blocks;
     n->filters = num_filters;
     return n;
@@ -197,6 +198,7 @@ oth_net* oth_net_create(int num_blocks, int num_filters, int board_size) {
 
 void oth_net_destroy(oth_net* net) {
     if (!net) return;
+    (void)bind_device(net->device);
     net_free_device(net);
     delete net;
 }
@@ -206,6 +208,7 @@ int64_t oth_net_state_floats(const oth_net* net) { return net ? state_floats(net
 int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int precision) {
     OTH_NEED_DEVICE();
     OTH_CHECK(net && blob, "oth_net_load_state: null argument");
+    OTH_BIND(net->device);
     OTH_CHECK(n_floats == state_floats(net->blocks, net->filters),
               "oth_net_load_state: got %lld floats, a %dx%d network has %lld", (long long)n_floats, net->blocks,
               net->filters, (long long)state_floats(net->blocks, net->filters));
@@ -255,6 +258,7 @@ int oth_net_forward_bits(oth_net* net, const uint64_t* sb, const uint64_t* ob, c
     OTH_CHECK(net && net->precision >= 0, "oth_net_forward: no weights loaded (call oth_net_load_state)");
     OTH_CHECK(n >= 0 && (n == 0 || (sb && ob && lg && logp && v)), "oth_net_forward: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND(net->device);
     if (net->precision != OTH_PREC_F32) return mfma_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     GenericArgs a;
     memset(&a, 0, sizeof(a));
@@ -266,7 +270,8 @@ int oth_net_forward_bits(oth_net* net, const uint64_t* sb, const uint64_t* ob, c
     }
     a.heads = net->heads;
     const size_t lds = (size_t)(3 * 64 * net->filters + 640) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};  // per device: the attribute belongs to the (function, device) pair
+    bool& attr_set = attr_set_dev[net->device & 63];
     if (!attr_set) {
         OTH_HIP(hipFuncSetAttribute((const void*)k_net_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -281,6 +286,7 @@ int oth_net_forward_planes(oth_net* net, const float* x, int64_t n, float* logp,
     OTH_NEED_DEVICE();
     OTH_CHECK(net && x && logp && v && n >= 0, "oth_net_forward_planes: bad arguments");
     if (n == 0) return OTH_OK;
+    OTH_BIND(net->device);
     uint64_t* bits = nullptr;
     OTH_HIP(hipMallocAsync((void**)&bits, sizeof(uint64_t) * 3 * n, as_stream(stream)));
     int64_t g = (n + 3) / 4;

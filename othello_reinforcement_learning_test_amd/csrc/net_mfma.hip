@@ -739,7 +739,8 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     OTH_HIP(hipMalloc(&a.dbg, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
     OTH_HIP(hipMemset(a.dbg, 0, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
 #endif
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};  // per device: the attribute belongs to the (function, device) pair
+    bool& attr_set = attr_set_dev[net->device & 63];
     constexpr int kLds2 = 2 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 2: 74 240 B, two workgroups per CU
     if (!attr_set) {
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));

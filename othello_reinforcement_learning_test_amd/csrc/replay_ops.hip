@@ -55,6 +55,7 @@ extern "C" int oth_augment_symmetries(const float* states, const float* pis, con
     OTH_CHECK(n >= 0 && (n == 0 || (states && pis && zs && states_out && pis_out && zs_out)),
               "oth_augment_symmetries: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(states);
     int64_t blocks = (n * 8 + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_symmetries, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), states, pis, zs, n,

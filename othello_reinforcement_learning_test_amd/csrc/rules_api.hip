@@ -39,6 +39,33 @@ bool device_ok() {
     return state == 1;
 }
 
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+
+int bind_device(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == dev) return OTH_OK;
+    OTH_HIP(hipSetDevice(dev));
+    return OTH_OK;
+}
+
+int bind_pointer_device(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pointer %p is not a HIP allocation (device memory expected)", p);
+        return OTH_E_INVALID;
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+        set_error("pointer %p is host memory; this call takes device pointers", p);
+        return OTH_E_INVALID;
+    }
+    return bind_device(at.device);
+}
+
 // -------------------------------------------------------------------------------- kernels
 __global__ void k_legal(const uint64_t* __restrict__ s, const uint64_t* __restrict__ o,
                         uint64_t* __restrict__ out, int64_t n) {
@@ -208,6 +235,7 @@ int oth_legal_moves_batch(const uint64_t* s, const uint64_t* o, uint64_t* legal,
     OTH_NEED_DEVICE();
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && legal)), "oth_legal_moves_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(s);
     hipLaunchKernelGGL(k_legal, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, legal, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
@@ -217,6 +245,7 @@ int oth_make_move_batch(uint64_t* s, uint64_t* o, const int32_t* pos, int32_t* o
     OTH_NEED_DEVICE();
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && pos && ok)), "oth_make_move_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(s);
     hipLaunchKernelGGL(k_make_move, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, pos, ok, flips, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
@@ -225,6 +254,7 @@ int oth_status_batch(const uint64_t* s, const uint64_t* o, int32_t* term, int32_
     OTH_NEED_DEVICE();
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && term && win)), "oth_status_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(s);
     hipLaunchKernelGGL(k_status, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, term, win, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
@@ -233,6 +263,7 @@ int oth_tensor_input_batch(const uint64_t* s, const uint64_t* o, float* out, int
     OTH_NEED_DEVICE();
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && out)), "oth_tensor_input_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(s);
     hipLaunchKernelGGL(k_tensor, dim3(grid_for((n + 3) / 4 * 256, 256)), dim3(256), 0, as_stream(stream), s, o, out, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;

@@ -106,8 +106,11 @@ class ParallelSelfPlayWorker:
         shares = [num_episodes // self.lanes + (1 if k < num_episodes % self.lanes else 0) for k in range(self.lanes)]
         out = [None] * self.lanes
 
+        dev = torch.cuda.current_device()
+
         def run(k):
-            with torch.cuda.stream(torch.cuda.Stream()):
+            torch.cuda.set_device(dev)   # per-thread state: a new thread starts on device 0
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
                 eng = self._lane_engines[k]
                 n = eng.selfplay_run(shares[k], seed + 7919 * (k + 1), add_dirichlet_noise)
                 out[k] = eng.selfplay_fetch(n)[:3]

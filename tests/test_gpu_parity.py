@@ -688,3 +688,49 @@ def test_lanes_overlap_mode(pkg):
         i += n
     assert len(gl) == 30 and sum(gl) == len(data)
     _check_replay_consistency(pkg, st, pi, z, np.array(gl), 8, onehot_late=False)
+
+
+def test_selfplay_full_size_properties(pkg):
+    """BASELINE.json configs[1] at full size: 4096 concurrent games, 50 sims/move, 10x128 network, two lanes.
+    The oracle cannot replay 12 M network evaluations in a test, so the run is checked through properties that
+    do not depend on size: every sample is a visit distribution of exactly 50 simulations over legal moves,
+    plane 2 is the oracle's legal mask of planes 0/1 (all samples, vectorised), z follows L16, the counters
+    balance, and 96 sampled games are walked move by move with the oracle's rules."""
+    torch.manual_seed(42)
+    net = pkg.OthelloResNet(10, 128).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=50, temperature_threshold=15,
+                                   num_parallel_games=4096, verbose=False, lanes=2)
+    np.random.seed(7)
+    st, pi, z = w._run_device(4096, True)
+    n = len(z)
+    c = {}
+    for eng in w._lane_engines:
+        for k, v in eng.counters().items():
+            c[k] = c.get(k, 0) + v
+    assert c["games"] == 4096 and c["plies"] == n and c["simulations"] == 50 * n
+    assert c["evals"] == n + c["simulations"] - c["terminal_sims"]
+    assert 4096 * 40 < n < 4096 * 75
+    # planes are 0/1, disjoint stones, and plane 2 == legal mask computed by the oracle from planes 0/1
+    assert bool(((st == 0) | (st == 1)).all())
+    assert not np.any((st[:, 0] == 1) & (st[:, 1] == 1))
+    weights = (np.uint64(1) << np.arange(64, dtype=U64)).reshape(8, 8)
+    sb = (st[:, 0].astype(U64) * weights).sum(axis=(1, 2), dtype=U64)
+    ob = (st[:, 1].astype(U64) * weights).sum(axis=(1, 2), dtype=U64)
+    lg = (st[:, 2].astype(U64) * weights).sum(axis=(1, 2), dtype=U64)
+    assert np.array_equal(ol.legal_batch(sb, ob), lg)
+    # pi: exactly 50 visits spread over legal moves (or all 50 on the pass move when there is none)
+    v50 = pi.astype(np.float64) * 50.0
+    assert np.abs(v50 - np.rint(v50)).max() < 1e-3 and np.abs(v50.sum(axis=1) - 50.0).max() < 1e-3
+    legal65 = np.concatenate([st[:, 2].reshape(n, 64) > 0, (lg == 0)[:, None]], axis=1)
+    assert not np.any((pi > 0) & ~legal65)
+    assert set(np.unique(z).tolist()) <= {-1.0, 0.0, 1.0}
+    # game boundaries: a sample equal to the start position with an even-ply successor chain; walk 96 games
+    start = ol.tensor(ol.board())
+    is_start = np.all(st == start[None], axis=(1, 2, 3))
+    firsts = np.flatnonzero(is_start)
+    assert len(firsts) == 4096 and firsts[0] == 0
+    lens = np.diff(np.append(firsts, n))
+    rng = np.random.default_rng(0)
+    for g in rng.choice(4096, 96, replace=False):
+        a, L = int(firsts[g]), int(lens[g])
+        _check_replay_consistency(pkg, st[a:a + L], pi[a:a + L], z[a:a + L], np.array([L]), 15, onehot_late=False)
