@@ -7,7 +7,7 @@ warmup steps, then exactly K timed steps bracketed by barrier + torch.cuda.synch
 ranks; rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch of synthetic input: every rank plays
-`--waves` x `--games` (default 2 x 4096) complete self-play games through `--games` = 4096 concurrent
+`--waves` x `--games` (default 3 x 4096) complete self-play games through `--games` = 4096 concurrent
 game slots (BASELINE.json configs[1]; finished slots are refilled; the slots are driven as `--lanes` = 2
 independent groups on two streams so that one group's trunk launches fill the other's tails and tree phases)
 from the initial position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games (= games per step) per GPU")
-    ap.add_argument("--waves", type=int, default=2,
+    ap.add_argument("--waves", type=int, default=3,
                     help="games per step per GPU = waves x --games, played through --games slots with refill")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=10)
