@@ -5,6 +5,8 @@
 // Two builds of the same design live here (DESIGN.md "K3" has the measurements that chose between them):
 //   k_trunk16<X3, TP>  SHIPPED: v_mfma_f32_16x16x32_f16, TP = 2 positions per workgroup, two workgroups per CU,
 //                      tiles = board row of a position pair (padding rows skipped).  Further down in this file.
+//                      TP = 1 (tile = two rows of one position) serves launches of <= 256 positions: half the
+//                      latency when every workgroup has a CU to itself anyway.
 //   k_trunk<X3>        first version, kept for A/B (OTH_MFMA_SHAPE=32): v_mfma_f32_32x32x16_f16, 4 positions per
 //                      workgroup, one workgroup per CU.
 //
@@ -364,7 +366,7 @@ __device__ __forceinline__ constexpr int valid_tile(int i) {
 }
 
 template <bool X3, int TP>
-__global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, const uint64_t* __restrict__ sb,
+__global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, const uint64_t* __restrict__ sb,
                                                                    const uint64_t* __restrict__ ob,
                                                                    const uint64_t* __restrict__ lgl, int64_t n,
                                                                    const int32_t* __restrict__ n_valid,
@@ -375,9 +377,9 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
 #ifndef OTH16_PB
 #define OTH16_PB 2
 #endif
-    constexpr int PD = (X3 || TP == 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
+    constexpr int PD = (X3 || TP <= 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
     constexpr int PB = OTH16_PB;    // weight k-steps (32 channels) in flight
-    constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row)
+    constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row); TP = 1: two rows
     constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
     constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -390,10 +392,13 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
     if (pos0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c16 = lane & 15;
-    const int pz = c16 >> 3, cx = c16 & 7;   // position within the pair, board column
-    // LDS cell index of this lane in tile t: ((2*(t>>3) + pz)*64 + (t&7)*8 + cx); lane part and tile part:
-    const uint32_t lane_cell = (uint32_t)(pz * 64 + cx);
-#define OTH_TILE_CELL(t) ((uint32_t)(((t) >> 3) * 128 + ((t) & 7) * 8))
+    const int pz = c16 >> 3, cx = c16 & 7;   // position within the pair (TP = 1: row parity), board column
+    // LDS cell index of this lane in tile t: ((2*(t>>3) + pz)*64 + (t&7)*8 + cx); lane part and tile part.
+    // TP = 1 (low-latency build for launches that do not fill the chip): a tile is rows 2t, 2t+1 of the one
+    // position, cell = 16 t + 8 pz + cx; the swizzle key then uses the row parity where the pair build uses the
+    // position bit, which keeps the lane groups of every ds_read_b128 on 16 different chunks in the same way.
+    const uint32_t lane_cell = TP == 1 ? (uint32_t)c16 : (uint32_t)(pz * 64 + cx);
+#define OTH_TILE_CELL(t) (TP == 1 ? (uint32_t)((t) * 16) : (uint32_t)(((t) >> 3) * 128 + ((t) & 7) * 8))
 
     if (tid < TP * 64) {  // stem input: im2col of the three bit planes, [TP*64 cells][32 k] f16, k = tap*3 + plane
         const int p = tid >> 6, c = tid & 63, y = c >> 3, x = c & 7;
@@ -522,17 +527,20 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
         // ---------------- conv `layer+1`: 3 row offsets (compile-time) x 3 column offsets x 4 k-steps x tiles
         auto tap_row = [&](auto DYC) {
             constexpr int DY = decltype(DYC)::value;
-            constexpr int NTV = DY == 0 ? NT : NT - NT / 8;  // tiles with in-board source rows
+            constexpr int NTV = (DY == 0 || TP == 1) ? NT : NT - NT / 8;  // tiles with in-board source rows
             constexpr int NQ = 4 * NTV;                      // (k-step, tile) fragments of one tap
             for (int dxi = 0; dxi < 3; ++dxi) {
                 const int tap = (DY + 1) * 3 + dxi;
                 const int xs = cx + dxi - 1;
                 const bool xok = xs >= 0 && xs < 8;
-                const uint32_t hk = (uint32_t)(g4 ^ swz16(xs, pz));
-                // this lane's source cell of tile t (row (t&7)+DY is in-board for every tile used here)
-                const int src_cell = pz * 64 + DY * 8 + xs;   // + OTH_TILE_CELL(t)
+                const uint32_t hk = (uint32_t)(g4 ^ swz16(xs, TP == 1 ? (pz ^ (DY & 1)) : pz));
+                // this lane's source cell of tile t.  Pair build: row (t&7)+DY is in-board for every tile used here.
+                // TP = 1: row 2t+pz+DY leaves the board only for (DY = -1, t = 0, pz = 0) and (DY = +1, t = 3, pz = 1).
+                const int src_cell = (TP == 1 ? pz * 8 : pz * 64) + DY * 8 + xs;   // + OTH_TILE_CELL(t)
+#define OTH_TILE_OF(i) (TP == 1 ? (i) % NTV : valid_tile<DY>((i) % NTV))
+#define OTH_ROW_OK(t) (TP != 1 || DY == 0 || (DY < 0 ? ((t) > 0 || pz != 0) : ((t) < 3 || pz == 0)))
 #define OTH_SRC(i)                                                                                                   \
-    (lds + ((xok ? (uint32_t)((int)OTH_TILE_CELL(valid_tile<DY>((i) % NTV)) + src_cell) * kCellBytes : (uint32_t)ZERO_OFF) | \
+    (lds + (((xok && OTH_ROW_OK(OTH_TILE_OF(i))) ? (uint32_t)((int)OTH_TILE_CELL(OTH_TILE_OF(i)) + src_cell) * kCellBytes : (uint32_t)ZERO_OFF) | \
             ((((uint32_t)(((i) / NTV) << 2)) ^ hk) << 4)))
                 half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
                             if (X3 || !(f & 1)) wq[slot][f] = wl[(size_t)nstep * 1024 + f * 64];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const int t = valid_tile<DY>(q % NTV);
+                    const int t = OTH_TILE_OF(q);
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
                         if (X3) {
@@ -574,6 +582,8 @@ __global__ __launch_bounds__(256, (TP == 4 ? 1 : 2)) void k_trunk16(MfmaArgs a, 
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef OTH_SRC
+#undef OTH_ROW_OK
+#undef OTH_TILE_OF
             }
         };
         tap_row(std::integral_constant<int, -1>{});
@@ -742,11 +752,13 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     static bool attr_set_dev[64] = {};  // per device: the attribute belongs to the (function, device) pair
     bool& attr_set = attr_set_dev[net->device & 63];
     constexpr int kLds2 = 2 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 2: 74 240 B, two workgroups per CU
+    constexpr int kLds1 = 1 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 1 (heads scratch needs the 8 KiB)
     if (!attr_set) {
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
         attr_set = true;
@@ -755,9 +767,15 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     const char* tpe = getenv("OTH_TRUNK_TP");
     // default: two 2-position workgroups per CU for the fp16x3 build; the single-pass build runs 4 positions per
     // workgroup (its TP = 2 instantiation spills registers)
-    const int tp = net->mfma->shape != 16 ? 4 : (tpe ? (atoi(tpe) == 4 ? 4 : 2) : (x3 ? 2 : 4));
+    // launches that cannot fill the chip (n <= 256: every workgroup has a CU to itself either way) run one
+    // position per workgroup -- twice the CUs, half the MFMAs per workgroup: 0.34 -> ~0.2 ms per launch
+    const int tp_auto = x3 ? (n <= 256 ? 1 : 2) : 4;
+    const int tp_env = tpe ? atoi(tpe) : 0;
+    const int tp = net->mfma->shape != 16 ? 4 : ((tp_env == 4 || tp_env == 2 || (tp_env == 1 && x3)) ? tp_env : tp_auto);
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
-    if (net->mfma->shape == 16 && tp == 2) {
+    if (net->mfma->shape == 16 && tp == 1) {
+        hipLaunchKernelGGL((k_trunk16<true, 1>), dim3(grid), dim3(256), kLds1, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    } else if (net->mfma->shape == 16 && tp == 2) {
         if (x3) hipLaunchKernelGGL((k_trunk16<true, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
         else hipLaunchKernelGGL((k_trunk16<false, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
     } else if (net->mfma->shape == 16) {
