@@ -64,7 +64,7 @@ class BatchMCTS:
 class ParallelSelfPlayWorker:
     def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
                  num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
-                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=1):
+                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=None):
         self.board_class = board_class
         self.num_simulations = num_simulations
         self.temperature_threshold = temperature_threshold
@@ -83,6 +83,8 @@ class ParallelSelfPlayWorker:
         # lanes > 1 (device RNG mode): the slots are split into independent groups, each an engine on its own
         # stream and host thread; their kernels overlap on the device (one group's network launches fill the
         # other's tails and tree-search phases: +4 % at 4096 slots).  Results are concatenated lane by lane.
+        if lanes is None:   # measured: two lanes pay off once each still fills the chip (2048 slots = 1024 workgroups)
+            lanes = 2 if num_parallel_games >= 4096 else 1
         self.lanes = max(1, int(lanes))
         self._lane_engines = [self.engine]
         if self.lanes > 1:
@@ -93,13 +95,16 @@ class ParallelSelfPlayWorker:
                                                evaluator=self.batch_mcts.evaluator, eval_cache_log2=eval_cache_log2)
                                   for _ in range(self.lanes)]
         self.last_stats = {}
+        self._ran = [self.engine]   # engines the last device-RNG call ran on
 
     # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------
     def _run_device(self, num_episodes, add_dirichlet_noise):
         seed = int(np.random.randint(0, 2**62))
         if self.lanes == 1 or num_episodes < 2 * self.lanes:
+            self._ran = [self.engine]
             n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
             return self.engine.selfplay_fetch(n)[:3]
+        self._ran = self._lane_engines
         import threading
 
         import torch
@@ -173,7 +178,7 @@ class ParallelSelfPlayWorker:
                 done += bs
         dt = time.time() - t0
         counters = {}
-        for eng in (self._lane_engines if self.lanes > 1 and self.rng_mode == "device" else [self.engine]):
+        for eng in (self._ran if self.rng_mode == "device" else [self.engine]):
             for k, v in eng.counters().items():
                 counters[k] = counters.get(k, 0) + v
         self.last_stats = {"games": num_episodes, "samples": len(data), "seconds": dt,

@@ -699,8 +699,9 @@ def test_selfplay_full_size_properties(pkg):
     torch.manual_seed(42)
     net = pkg.OthelloResNet(10, 128).eval()
     w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=50, temperature_threshold=15,
-                                   num_parallel_games=4096, verbose=False, lanes=2)
+                                   num_parallel_games=4096, verbose=False)
     np.random.seed(7)
+    assert w.lanes == 2     # picked automatically at this size
     st, pi, z = w._run_device(4096, True)
     n = len(z)
     c = {}
