@@ -113,12 +113,14 @@ def main():
     eng = engs[0]
     streams = [torch.cuda.Stream(device=torch.cuda.current_device()) for _ in range(lanes)] if lanes > 1 else [None]
 
-    gloo = world > 1 and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
+    # OTHELLO_FORCE_DIST=1 under torchrun --nproc-per-node 1: run the RCCL calls of the N>1 path on a one-rank group
+    use_dist = world > 1 or (dist.is_available() and dist.is_initialized())
+    gloo = use_dist and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
 
     dev = torch.cuda.current_device()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if gloo:
                 dist.barrier()
             else:
@@ -146,10 +148,10 @@ def main():
                 t_.join()
             parts = [e_.selfplay_device_tensors() for e_ in engs]
             st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
-        if world > 1:   # the one exchange step: RCCL all-gather of the replay tuples
+        if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
             if gloo:
                 st, pi, z = st.cpu(), pi.cpu(), z.cpu()
-            st, pi, z, _ = D.all_gather_replay(st, pi, z)
+            st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)
         return int(z.shape[0])
 
     barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
@@ -183,7 +185,7 @@ def main():
         union_ms += cur_e - cur_s
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -256,8 +258,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -22,14 +22,14 @@ def shard_episodes(num_episodes, rank, world_size):
     return int((num_episodes - rank + world_size - 1) // world_size) if num_episodes > rank else 0
 
 
-def all_gather_replay(states, pis, zs, group=None):
+def all_gather_replay(states, pis, zs, group=None, force=False):
     """All-gather variable-length replay tuples.  Inputs are torch tensors on one device (CUDA for
     RCCL, CPU for gloo) with a common leading length n_r.  Returns (states, pis, zs, counts) where the
     arrays are the concatenation over ranks in rank order and counts[r] = n_r."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return states, pis, zs, [int(zs.shape[0])]
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return states, pis, zs, [int(zs.shape[0])]   # force=True runs the collectives on a one-rank group (RCCL smoke test)
     world = dist.get_world_size(group)
     dev = zs.device
     n = torch.tensor([zs.shape[0]], dtype=torch.int64, device=dev)
@@ -99,7 +99,8 @@ def init_from_env(backend=None):
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if ndev:
         torch.cuda.set_device(local % ndev)   # one GPU per rank on a real node; shared only in rehearsals
-    if world > 1 and not dist.is_initialized():
+    force = bool(os.environ.get("OTHELLO_FORCE_DIST")) and "RANK" in os.environ   # one-rank RCCL smoke test
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
