@@ -171,6 +171,25 @@ def test_search_deep_tree_400_sims(pkg, g3):
         assert np.array_equal(visits[i], on) and np.array_equal(wsum[i], ow)
 
 
+def test_search_maximum_simulations(pkg, g3):
+    """Largest search the engine accepts (oth_engine_cfg.num_simulations = 4000: the descent path of a workgroup's
+    four games just fits 64 KiB of LDS, visit counters are u16, child links u16): still bit-exact against the oracle,
+    including an end-game position whose tree saturates with terminal leaves.  4001 is rejected."""
+    table = g3["stub_exp"]
+    ev = ol.make_eval(lambda s, o: stub_probs_values(s, o, table))
+    pos = game_positions(3, 9)
+    pick = [pos[3], pos[40], [p for p in pos if p[2] >= 52][0]]
+    eng = pkg.SearchEngine(len(pick), 4000, c_puct=1.0)
+    pi, visits, wsum, _ = eng.search_with([p[0] for p in pick], [p[1] for p in pick],
+                                          lambda s, o, lg: stub_probs_values(s, o, table))
+    assert visits.sum(axis=1).tolist() == [4000] * len(pick) and visits.max() > 1000
+    for i, (s, o, _) in enumerate(pick):
+        opi, on, ow, _ = ol.search(ol.board(s, o), 4000, 1.0, 1.0, ev)
+        assert np.array_equal(visits[i], on) and np.array_equal(wsum[i], ow) and np.array_equal(pi[i], opi)
+    with pytest.raises(Exception):
+        pkg.SearchEngine(1, 4001)
+
+
 def test_best_action_and_evaluations_vs_reference(pkg, g3):
     """get_best_action / get_action_evaluations (reference mcts.py:257-362) from the device search statistics,
     against the reference's answers under the stub evaluator."""
