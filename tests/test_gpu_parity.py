@@ -754,3 +754,29 @@ def test_selfplay_full_size_properties(pkg):
     for g in rng.choice(4096, 96, replace=False):
         a, L = int(firsts[g]), int(lens[g])
         _check_replay_consistency(pkg, st[a:a + L], pi[a:a + L], z[a:a + L], np.array([L]), 15, onehot_late=False)
+
+
+def test_no_device_memory_growth(pkg):
+    """Repeated runs of different sizes on one engine, plus engine / evaluator create-destroy cycles, must not
+    leak device memory (hipMemGetInfo before and after; the library allocates with hipMalloc, outside torch's
+    caching allocator)."""
+    torch.manual_seed(2)
+    net = pkg.OthelloResNet(2, 16).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=5, temperature_threshold=6,
+                                   num_parallel_games=64, verbose=False)
+    np.random.seed(0)
+    w.execute_episodes(200)          # largest run first: output buffers reach their final capacity
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in (7, 200, 64, 1, 130, 200):
+        assert len(w.execute_episodes(n)) > 9 * n
+    for _ in range(5):
+        w2 = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=5, temperature_threshold=6,
+                                        num_parallel_games=32, verbose=False, eval_cache_log2=12)
+        w2.execute_episodes(40)
+        del w2
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes" % (free0 - free1)
