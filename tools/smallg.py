@@ -1,0 +1,25 @@
+"""Small-engine rate (the reference's own kind of configuration: few parallel games, few simulations) without the
+timing hooks, e.g. to compare OTH_GRAPH=0/1.  usage: smallg.py [sims]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import othello_reinforcement_learning_test_amd as pkg
+
+sims = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+torch.manual_seed(42)
+net = pkg.OthelloResNet(10, 128).eval()
+ev = pkg.HipResNetEvaluator(net)
+for G in (1, 8, 32, 256):
+    eng = pkg.SearchEngine(G, sims, temperature_threshold=15, evaluator=ev)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        eng.selfplay_run(G, 1, True)
+        t0 = time.time()
+        n = eng.selfplay_run(2 * G, 7, True)
+        dt = time.time() - t0
+    st, pi, z, gl = eng.selfplay_fetch(n)
+    print("G=%d sims=%d: %.1f games/s (%d samples, checksum %.6f, %d net batches)" %
+          (G, sims, 2 * G / dt, n, float(pi.astype(np.float64).sum() + st.sum() + z.sum()), eng.counters()["net_batches"]), flush=True)
