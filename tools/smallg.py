@@ -1,5 +1,5 @@
 """Small-engine rate (the reference's own kind of configuration: few parallel games, few simulations) without the
-timing hooks, e.g. to compare OTH_GRAPH=0/1.  usage: smallg.py [sims]"""
+timing hooks.  usage: smallg.py [sims]"""
 import sys
 import time
 
