@@ -25,6 +25,9 @@
 //     lo parts in the normal f16 range; it is undone exactly on the fp32 accumulator.
 //   * LDS bank conflicts: the 16-byte chunk index of a cell is XORed with a key derived from the source cell so that
 //     the 16 lanes of every ds_read_b128 group hit 16 different slots for all nine taps (tools/lds_bank_model.py).
+//   * the chip is power/clock-limited on this code (76 % matrix-pipe busy at ~1.76 of 2.4 GHz), so instruction ORDER
+//     matters: the three split products of an accumulator issue back to back with one operand changing at a time
+//     (k_trunk16's tile body): same instructions, -4 % time.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
