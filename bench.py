@@ -67,6 +67,20 @@ def cpu_baseline(net, sims, budget_s):
     }
 
 
+def proportional_shares(rates, nominal, lanes):
+    """Games per rank for the next step: proportional to the measured rates, within +-10 % of `nominal`, every share a
+    multiple of `lanes`, job total exactly len(rates) * nominal (the rounding remainder goes to the fastest rank)."""
+    import numpy as np
+    rate = np.asarray(rates, dtype=np.float64)
+    world = len(rate)
+    if not np.all(np.isfinite(rate)) or rate.min() <= 0:
+        return [nominal] * world
+    want = np.clip(nominal * world * rate / rate.sum(), 0.9 * nominal, 1.1 * nominal)
+    new = [int(w) // lanes * lanes for w in want]
+    new[int(np.argmax(rate))] += nominal * world - sum(new)
+    return new
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +98,8 @@ def main():
                          "thread (their kernels overlap: tails and tree phases of one lane are filled by the other)")
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="log2 entries of the opt-in evaluation cache (0 = off; the headline number is measured with it OFF)")
+    ap.add_argument("--equal-shares", action="store_true",
+                    help="N>1: give every rank exactly --waves x --games per step instead of rate-proportional shares")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     args = ap.parse_args()
@@ -127,44 +143,68 @@ def main():
                 dist.barrier(device_ids=[dev])
         torch.cuda.synchronize()
 
-    def run_lane(k, i):
+    # Games per step: world x waves x games in total.  MI355X devices sustain clocks several per cent apart on this
+    # MFMA-dense work, and the ranks meet at every step's all-gather, so equal shares would run the job at the pace of
+    # its slowest GPU.  Each rank's share of the NEXT step follows its measured rate in the step before (shares are
+    # computed identically on every rank from one tiny all-gather, kept within +-10 % of equal, total unchanged).
+    nominal = args.games * args.waves
+    shares = [nominal] * world
+    played = [0]   # games played by the whole job so far in the timed region (filled by step())
+
+    def rebalance(my_games, my_seconds):
+        if world == 1 or args.equal_shares:
+            return
+        t = torch.tensor([my_games / max(my_seconds, 1e-6)], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        allr = torch.zeros(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allr, t)
+        shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
+
+    def run_lane(k, i, n_lane):
         torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
         seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
         if streams[k] is None:
-            engs[k].selfplay_run(args.games * args.waves // lanes, seed, add_noise=True)
+            engs[k].selfplay_run(n_lane, seed, add_noise=True)
         else:
             with torch.cuda.stream(streams[k]):
-                engs[k].selfplay_run(args.games * args.waves // lanes, seed, add_noise=True)
+                engs[k].selfplay_run(n_lane, seed, add_noise=True)
 
     def step(i):
+        mine = shares[rank]
+        played[0] += sum(shares)
+        t_play = time.time()
         if lanes == 1:
-            run_lane(0, i)
+            run_lane(0, i, mine)
             st, pi, z = eng.selfplay_device_tensors()
         else:
-            ths = [threading.Thread(target=run_lane, args=(k, i)) for k in range(lanes)]
+            ths = [threading.Thread(target=run_lane, args=(k, i, mine // lanes)) for k in range(lanes)]
             for t_ in ths:
                 t_.start()
             for t_ in ths:
                 t_.join()
             parts = [e_.selfplay_device_tensors() for e_ in engs]
             st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
+        t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
             if gloo:
                 st, pi, z = st.cpu(), pi.cpu(), z.cpu()
             st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)
+        rebalance(mine, t_play)
         return int(z.shape[0])
 
     barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
     for i in range(args.warmup):
         step(i)
     barrier()
+    played[0] = 0
     t0 = time.time()
     samples = 0
     stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0,
              "cache_hits": 0}
     kt = {"net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0}
     union_ms = 0.0   # time during which at least one trunk launch was running (lanes overlap)
+    last_shares = list(shares)
     for i in range(args.steps):
+        last_shares = list(shares)
         samples = step(args.warmup + i)
         spans = []
         for e_ in engs:
@@ -189,7 +229,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_games = args.games * args.waves * args.steps * world
+    total_games = played[0]
+    assert total_games == args.games * args.waves * args.steps * world
 
     if rank == 0:
         traffic = None   # HBM-side bytes per k_trunk launch from the committed PMC profile (4096 positions)
@@ -229,6 +270,9 @@ def main():
                 "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
                                                             if world > 1 else "single GPU"),
                 "lanes_per_gpu": lanes,
+                "games_per_rank_last_step": ("equal" if world == 1 or args.equal_shares else
+                                             "proportional to each rank's measured rate in the previous step "
+                                             "(+-10 %% of equal, job total fixed): %s" % last_shares),
                 "eval_cache": ("off (every position the search reaches is evaluated by the network)" if not args.eval_cache
                                else "ON: 2^%d entries, %d hits -- NOT the headline configuration" % (args.eval_cache, stats["cache_hits"])),
                 "samples_last_step": samples,

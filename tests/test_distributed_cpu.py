@@ -73,3 +73,27 @@ def test_single_process_is_identity():
     st, pi, z = _make(0, 10)
     a, b, c, counts = all_gather_replay(st, pi, z)
     assert a is st and b is pi and c is z and counts == [10]
+
+
+def test_bench_proportional_shares():
+    """bench.py's N>1 load balancing: shares follow the measured rates, stay within 10 % of equal, are multiples of the
+    lane count and keep the job total fixed; degenerate inputs fall back to equal shares."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nominal, lanes = 12288, 2
+    rates = [500.0, 520.0, 480.0, 510.0, 495.0, 530.0, 470.0, 505.0]
+    s = bench.proportional_shares(rates, nominal, lanes)
+    assert sum(s) == nominal * 8 and all(x % lanes == 0 for x in s)
+    assert all(0.9 * nominal <= x <= 1.1 * nominal + lanes * 8 for x in s)
+    order = sorted(range(8), key=lambda i: rates[i])
+    assert [s[i] for i in order] == sorted(s)                       # faster rank, more games
+    finish = [s[i] / rates[i] for i in range(8)]
+    assert max(finish) / min(finish) < 1.002                        # everybody finishes together
+    assert max(nominal / r for r in rates) / (sum(finish) / 8) > 1.05   # equal shares would have cost > 5 %
+    assert bench.proportional_shares([1.0, 0.0], nominal, lanes) == [nominal, nominal]
+    assert bench.proportional_shares([1.0, float("nan")], nominal, lanes) == [nominal, nominal]
+    s = bench.proportional_shares([100.0, 300.0], nominal, lanes)   # clamp at +-10 %
+    assert sum(s) == 2 * nominal and min(s) >= int(0.9 * nominal) - lanes
