@@ -33,6 +33,14 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
 
 MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
+
+
+def mflop_per_position(blocks, filters):
+    """Algorithmic MFLOP of one forward pass (2 x MACs): stem 3x3x3 -> F, 2*blocks 3x3 F -> F convs on 64 cells, the two
+    1x1 head convs and the three head FCs.  10x128: 189 014 400 MACs = 378.03 MFLOP."""
+    f = filters
+    macs = 64 * 27 * f + 2 * blocks * 64 * 9 * f * f + 64 * f * 2 + 64 * f + 128 * 65 + 64 * 256 + 256
+    return 2.0 * macs / 1e6
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PLIES_PER_GAME = 61.0           # BASELINE.md work model (used only to scale the CPU sample)
 
@@ -242,7 +250,7 @@ def main():
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
         # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
         net_s = union_ms * 1e-3
-        flops = stats["evals"] * MFLOP_PER_POSITION * 1e6
+        flops = stats["evals"] * mflop_per_position(args.blocks, args.filters) * 1e6
         achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
         prec = ev.precision
         # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
