@@ -2,8 +2,8 @@
 """Build the REFERENCE's own Cython bitboard into oracle/_ref/ (test infrastructure only).
 
 The sources stay where they lie under /root/reference (src/cython/bitboard.pyx + .pxd); only
-build outputs (generated C, object code, the extension module) land in oracle/_ref/, which is
-git-ignored.  Compile directives follow the reference's own recipe (/root/reference/setup.py:22-30:
+build outputs land in oracle/_ref/, which is git-ignored; the generated C file is deleted again once the
+extension module is compiled, so that only machine code is kept (and travels to the GPU box).  Compile directives follow the reference's own recipe (/root/reference/setup.py:22-30:
 -O3, language_level 3, boundscheck/wraparound off, cdivision on).
 
 Nothing in the product path (othello_reinforcement_learning_test_amd/) imports this.  Used by
@@ -52,6 +52,7 @@ def build(force=False):
         "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION",
         "-I", inc, "-I", np.get_include(), c_file, "-o", so,
     ])
+    os.remove(c_file)   # keep only the compiled module: the generated C is a transcript of the reference source
     return so
 
 
