@@ -167,14 +167,19 @@ def main():
         dist.all_gather_into_tensor(allr, t)
         shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
 
+    lane_errors = []
+
     def run_lane(k, i, n_lane):
-        torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
-        seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
-        if streams[k] is None:
-            engs[k].selfplay_run(n_lane, seed, add_noise=True)
-        else:
-            with torch.cuda.stream(streams[k]):
+        try:
+            torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
+            seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
+            if streams[k] is None:
                 engs[k].selfplay_run(n_lane, seed, add_noise=True)
+            else:
+                with torch.cuda.stream(streams[k]):
+                    engs[k].selfplay_run(n_lane, seed, add_noise=True)
+        except BaseException as exc:   # a failing lane must fail the whole bench, not leave stale tuples behind
+            lane_errors.append(exc)
 
     def step(i):
         mine = shares[rank]
@@ -182,6 +187,8 @@ def main():
         t_play = time.time()
         if lanes == 1:
             run_lane(0, i, mine)
+            if lane_errors:
+                raise lane_errors[0]
             st, pi, z = eng.selfplay_device_tensors()
         else:
             ths = [threading.Thread(target=run_lane, args=(k, i, mine // lanes)) for k in range(lanes)]
@@ -189,6 +196,8 @@ def main():
                 t_.start()
             for t_ in ths:
                 t_.join()
+            if lane_errors:
+                raise lane_errors[0]
             parts = [e_.selfplay_device_tensors() for e_ in engs]
             st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
         t_play = time.time() - t_play

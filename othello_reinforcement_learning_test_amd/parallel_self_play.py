@@ -113,17 +113,24 @@ class ParallelSelfPlayWorker:
 
         dev = torch.cuda.current_device()
 
+        errors = []
+
         def run(k):
-            torch.cuda.set_device(dev)   # per-thread state: a new thread starts on device 0
-            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                eng = self._lane_engines[k]
-                n = eng.selfplay_run(shares[k], seed + 7919 * (k + 1), add_dirichlet_noise)
-                out[k] = eng.selfplay_fetch(n)[:3]
+            try:
+                torch.cuda.set_device(dev)   # per-thread state: a new thread starts on device 0
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    eng = self._lane_engines[k]
+                    n = eng.selfplay_run(shares[k], seed + 7919 * (k + 1), add_dirichlet_noise)
+                    out[k] = eng.selfplay_fetch(n)[:3]
+            except BaseException as exc:   # re-raised in the calling thread: a failed lane fails the call
+                errors.append(exc)
         threads = [threading.Thread(target=run, args=(k,)) for k in range(self.lanes)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+        if errors:
+            raise errors[0]
         return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
 
     # ---- numpy RNG: the reference's lock-step batches, draws in the reference's order --------
