@@ -4,22 +4,26 @@
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one process
 per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env).  W untimed
 warmup steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize(), MAX over
-ranks; rank 0 prints ONE JSON line.
+ranks; rank 0 prints ONE JSON line on stdout (and a heartbeat line per step on stderr).
 
-A "step" = one pass of the hot path over one batch of synthetic input: every rank plays
-`--waves` x `--games` (default 3 x 4096) complete self-play games through `--games` = 4096 concurrent
-game slots (BASELINE.json configs[1]; finished slots are refilled; the slots are driven as `--lanes` = 2
-independent groups on two streams so that one group's trunk launches fill the other's tails and tree phases)
-from the initial position -- 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), 50
-simulations per move, c_puct 1.0, temperature threshold 15 -- entirely on the device, and (N>1)
-the ranks all-gather the replay tuples over RCCL.  value = games completed by all ranks / time.
+Workload (BASELINE.json configs[1]): 4096 concurrent 8x8 self-play games per GPU, 50 simulations per move,
+10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), c_puct 1.0, temperature
+threshold 15, every position the search reaches evaluated by the network -- entirely on the device.
 
-Extra objects on the same line:
-  roofline     dominant kernel = the fused ResNet trunk (k_trunk): algorithmic FLOPs (378.03 MFLOP per
-               evaluated position) / its summed launch time, measured live with HIP events on
-               the launch stream, against the dense fp16 MFMA peak (2.5 PFLOP/s).
-  cpu_baseline the CPU oracle (a C port of the reference algorithm, oracle/) timed on the host cores
-               over a bounded sample of the same workload.  Reported, not targeted.
+A "step" = one pass of the hot path over one batch: the 4096 game slots of a rank play at STEADY STATE
+(streaming mode: finished slots are refilled at once and games stay in flight between steps, so a step has
+no ragged tail) until `--step-games` (default 1536) more games per GPU have finished; their (state, pi, z)
+replay tuples are compacted in HBM and (N>1) all-gathered over RCCL.  value = games completed by all ranks
+during the timed steps / time.  The slots are driven as `--lanes` = 2 independent groups on two streams so
+that one group's trunk launches fill the other's tails and tree phases.
+
+The timed steps run with the engine's HIP-event hooks OFF.  After the timed region one extra PROFILED step
+(hooks on, not part of `value`) measures the dominant kernel live for the roofline object:
+  roofline     k_trunk (fused ResNet forward): algorithmic FLOPs (378.03 MFLOP per evaluated position,
+               SURVEY 8(d)) / the time during which a trunk launch was running (HIP events on the launch
+               streams), against the dense fp16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline the CPU oracle (a C port of the reference algorithm, oracle/) timed on the host cores over a
+               bounded, phase-uniform sample of the same workload.  Reported, not targeted.
 """
 import argparse
 import ctypes as C
@@ -33,6 +37,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
 
 MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
+PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+PLIES_PER_GAME = 60.7           # measured by the engine over >100k games of this workload
+# Planning figure for the time budget only (tests/test_bench_budget.py): games/s one MI355X sustains on the default
+# workload, taken well below the slowest box measured (503-528 in round 1).
+PLANNING_RATE = 420.0
 
 
 def mflop_per_position(blocks, filters):
@@ -41,13 +50,21 @@ def mflop_per_position(blocks, filters):
     f = filters
     macs = 64 * 27 * f + 2 * blocks * 64 * 9 * f * f + 64 * f * 2 + 64 * f + 128 * 65 + 64 * 256 + 256
     return 2.0 * macs / 1e6
-PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
-PLIES_PER_GAME = 61.0           # BASELINE.md work model (used only to scale the CPU sample)
 
 
-def cpu_baseline(net, sims, budget_s):
-    """Time the oracle (kind 'port') on the host cores: one independent serial self-play stream per
-    core, bounded to a few plies each, scaled to games/s with the 61-plies-per-game work model."""
+def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_steps=1, cpu_budget=15.0,
+                    rate=PLANNING_RATE, startup=150.0):
+    """Wall-clock plan of one bench.py run on one MI355X (default workload): process start-up (the first
+    `import torch` on a fresh box can take 2 minutes) + staggered ramp + (warmup + steps + profiled) steps +
+    CPU baseline."""
+    ramp = 0.5 * slots * min(stagger, 61) / 61.0 / rate          # half-full slots during the staggered start
+    return startup + ramp + (warmup + steps + profile_steps) * step_games / rate + cpu_budget + 10.0
+
+
+def cpu_baseline(net, sims, budget_s, evals_per_game):
+    """Time the oracle (kind 'port') on the host cores: one serial self-play stream per core, each starting at a
+    different phase of a game (so openings, middle games and endgames are sampled like a whole game), a bounded
+    number of plies each."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     try:
@@ -58,21 +75,26 @@ def cpu_baseline(net, sims, budget_s):
     cfg = ol.SelfplayCfg(sims, 15, 1, 1.0, 0.3, 0.25, 1, 0)
 
     def run(plies):
-        ev, th = C.c_int64(0), C.c_int(0)
+        ev, th, ended = C.c_int64(0), C.c_int(0), C.c_int64(0)
         t0 = time.time()
-        n = ol.lib().orc_cpu_baseline(onet.h, C.byref(cfg), cores, plies, 42, C.byref(ev), C.byref(th))
+        n = ol.lib().orc_cpu_baseline_spread(onet.h, C.byref(cfg), cores, plies, 58, 42, C.byref(ev), C.byref(th),
+                                             C.byref(ended))
         return n, ev.value, th.value, time.time() - t0
     n, ev, th, dt = run(1)                       # calibration: one ply per stream
     plies = max(1, min(20, int(budget_s / max(dt, 1e-3))))
     if plies > 1:
         n, ev, th, dt = run(plies)
-    return {
+    out = {
         "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th, "kind": "port",
-        "sample": "%d plies (%d network evals) over %d independent games, first %d plies each, "
-                  "10x128 net fp32, %d sims/move, %.1f s; scaled with 61 plies/game"
-                  % (n, ev, cores, plies, sims, dt),
+        "sample": "%d plies (%d network evals) of serial self-play on %d streams, stream s starting 58*s/%d random "
+                  "plies into a game (phase-uniform: openings to endgames), %d plies each, 10x128 net fp32, %d "
+                  "sims/move, %.1f s; scaled with %.1f plies/game (the engine's measured game length)"
+                  % (n, ev, cores, cores, plies, sims, dt, PLIES_PER_GAME),
         "evals_per_s": round(ev / dt, 1),
     }
+    if evals_per_game:
+        out["value_by_evals"] = round(ev / dt / evals_per_game, 5)
+    return out
 
 
 def proportional_shares(rates, nominal, lanes):
@@ -89,14 +111,32 @@ def proportional_shares(rates, nominal, lanes):
     return new
 
 
+def union_ms(spans):
+    """Total length of the union of (start, end) intervals (ms); `spans` = list of (n, 2) arrays."""
+    import numpy as np
+    spans = [s for s in spans if len(s)]
+    if not spans:
+        return 0.0
+    sp = np.concatenate(spans)
+    sp = sp[np.argsort(sp[:, 0])]
+    total, (cur_s, cur_e) = 0.0, sp[0]
+    for s_, e2 in sp[1:]:
+        if s_ > cur_e:
+            total += cur_e - cur_s
+            cur_s, cur_e = s_, e2
+        else:
+            cur_e = max(cur_e, e2)
+    return float(total + (cur_e - cur_s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games (= games per step) per GPU")
-    ap.add_argument("--waves", type=int, default=3,
-                    help="games per step per GPU = waves x --games, played through --games slots with refill")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent game slots per GPU")
+    ap.add_argument("--step-games", type=int, default=1536,
+                    help="a step ends when this many more games per GPU have finished (steady state, slots stay full)")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
@@ -104,15 +144,20 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="independent game groups per GPU, each --games/--lanes slots on its own stream and host "
                          "thread (their kernels overlap: tails and tree phases of one lane are filled by the other)")
+    ap.add_argument("--stagger", type=int, default=61,
+                    help="slots join over this many ply rounds at stream start, so game phases are spread evenly and "
+                         "games finish at a steady rate from the first timed step on (0: all at once)")
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="log2 entries of the opt-in evaluation cache (0 = off; the headline number is measured with it OFF)")
     ap.add_argument("--equal-shares", action="store_true",
-                    help="N>1: give every rank exactly --waves x --games per step instead of rate-proportional shares")
+                    help="N>1: every rank targets exactly --step-games per step instead of rate-proportional shares")
+    ap.add_argument("--profile-steps", type=int, default=1, help="extra steps after the timed region with HIP-event hooks on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     args = ap.parse_args()
 
-    import numpy as np
+    t_start = time.time()
+    import numpy as np  # noqa: F401
     import torch
 
     import othello_reinforcement_learning_test_amd as pkg
@@ -124,24 +169,24 @@ def main():
     pkg._lib.require_device()   # no GPU => fail loudly
     import torch.distributed as dist
 
+    def beat(msg):
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
     torch.manual_seed(42)
     net = pkg.OthelloResNet(args.blocks, args.filters).eval()
     ev = pkg.HipResNetEvaluator(net, precision=args.precision)
     import threading
     lanes = max(1, args.lanes)
-    assert args.games % lanes == 0
+    assert args.games % lanes == 0 and args.step_games % lanes == 0
     engs = [pkg.SearchEngine(args.games // lanes, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev,
                              eval_cache_log2=args.eval_cache) for _ in range(lanes)]
-    for e_ in engs:
-        e_.set_timing(True)
-    eng = engs[0]
-    streams = [torch.cuda.Stream(device=torch.cuda.current_device()) for _ in range(lanes)] if lanes > 1 else [None]
+    dev = torch.cuda.current_device()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else [None]
 
     # OTHELLO_FORCE_DIST=1 under torchrun --nproc-per-node 1: run the RCCL calls of the N>1 path on a one-rank group
     use_dist = world > 1 or (dist.is_available() and dist.is_initialized())
     gloo = use_dist and dist.get_backend() == "gloo"   # rehearsal mode: collectives on host copies
-
-    dev = torch.cuda.current_device()
 
     def barrier():
         if use_dist:
@@ -151,13 +196,12 @@ def main():
                 dist.barrier(device_ids=[dev])
         torch.cuda.synchronize()
 
-    # Games per step: world x waves x games in total.  MI355X devices sustain clocks several per cent apart on this
-    # MFMA-dense work, and the ranks meet at every step's all-gather, so equal shares would run the job at the pace of
-    # its slowest GPU.  Each rank's share of the NEXT step follows its measured rate in the step before (shares are
-    # computed identically on every rank from one tiny all-gather, kept within +-10 % of equal, total unchanged).
-    nominal = args.games * args.waves
+    # Per-step target of each rank.  MI355X devices sustain clocks several per cent apart on this MFMA-dense work,
+    # and the ranks meet at every step's all-gather, so equal targets would run the job at the pace of its slowest
+    # GPU.  Each rank's target for the NEXT step follows its measured rate in the step before (computed identically
+    # on every rank from one tiny all-gather, kept within +-10 % of equal, job total unchanged).
+    nominal = args.step_games
     shares = [nominal] * world
-    played = [0]   # games played by the whole job so far in the timed region (filled by step())
 
     def rebalance(my_games, my_seconds):
         if world == 1 or args.equal_shares:
@@ -167,104 +211,134 @@ def main():
         dist.all_gather_into_tensor(allr, t)
         shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
 
-    lane_errors = []
+    def all_lanes(fn):
+        """Run fn(engine, lane) for every lane -- each on its own stream and host thread -- and return the results."""
+        out, errors = [None] * lanes, []
 
-    def run_lane(k, i, n_lane):
-        try:
-            torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
-            seed = 42 + 1000003 * ((i * world + rank) * lanes + k)
-            if streams[k] is None:
-                engs[k].selfplay_run(n_lane, seed, add_noise=True)
-            else:
-                with torch.cuda.stream(streams[k]):
-                    engs[k].selfplay_run(n_lane, seed, add_noise=True)
-        except BaseException as exc:   # a failing lane must fail the whole bench, not leave stale tuples behind
-            lane_errors.append(exc)
-
-    def step(i):
-        mine = shares[rank]
-        played[0] += sum(shares)
-        t_play = time.time()
+        def work(k):
+            try:
+                torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
+                if streams[k] is None:
+                    out[k] = fn(engs[k], k)
+                else:
+                    with torch.cuda.stream(streams[k]):
+                        out[k] = fn(engs[k], k)
+            except BaseException as exc:   # a failing lane must fail the whole bench, not leave stale tuples behind
+                errors.append(exc)
         if lanes == 1:
-            run_lane(0, i, mine)
-            if lane_errors:
-                raise lane_errors[0]
-            st, pi, z = eng.selfplay_device_tensors()
+            work(0)
         else:
-            ths = [threading.Thread(target=run_lane, args=(k, i, mine // lanes)) for k in range(lanes)]
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
             for t_ in ths:
                 t_.start()
             for t_ in ths:
                 t_.join()
-            if lane_errors:
-                raise lane_errors[0]
-            parts = [e_.selfplay_device_tensors() for e_ in engs]
-            st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
+        if errors:
+            raise errors[0]
+        return out
+
+    all_lanes(lambda e, k: e.stream_begin(42 + 1000003 * (rank * lanes + k), stagger_rounds=args.stagger))
+
+    def step():
+        """-> (games this rank finished, replay samples of the whole job after the exchange)"""
+        mine = shares[rank]
+        t_play = time.time()
+        res = all_lanes(lambda e, k: e.stream_step(mine // lanes))
+        games = sum(r[0] for r in res)
+        parts = [e_.selfplay_device_tensors() for e_ in engs]
         t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
+            st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
             if gloo:
                 st, pi, z = st.cpu(), pi.cpu(), z.cpu()
             st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)
-        rebalance(mine, t_play)
-        return int(z.shape[0])
+            samples = int(z.shape[0])
+        else:          # single GPU: the tuples stay where the lanes compacted them (no copy)
+            samples = sum(int(p_[2].shape[0]) for p_ in parts)
+        rebalance(games, t_play)
+        return games, samples
 
-    barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    played[0] = 0
-    t0 = time.time()
-    samples = 0
-    stats = {"evals": 0, "simulations": 0, "plies": 0, "games": 0, "net_batches": 0, "terminal_sims": 0,
-             "cache_hits": 0}
-    kt = {"net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0}
-    union_ms = 0.0   # time during which at least one trunk launch was running (lanes overlap)
-    last_shares = list(shares)
-    for i in range(args.steps):
-        last_shares = list(shares)
-        samples = step(args.warmup + i)
-        spans = []
+    def counters():
+        tot = {}
         for e_ in engs:
             for k, v in e_.counters().items():
-                stats[k] += v
-            for k, v in e_.kernel_time().items():
-                kt[k] += v
-            spans.append(e_.net_spans())
-        sp = np.concatenate(spans)
-        sp = sp[np.argsort(sp[:, 0])]
-        cur_s, cur_e = sp[0]
-        for s_, e2 in sp[1:]:
-            if s_ > cur_e:
-                union_ms += cur_e - cur_s
-                cur_s, cur_e = s_, e2
-            else:
-                cur_e = max(cur_e, e2)
-        union_ms += cur_e - cur_s
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    beat("setup done (%dx%d net, %d slots in %d lanes, %d sims); warm-up: %d steps of %d games"
+         % (args.blocks, args.filters, args.games, lanes, args.sims, args.warmup, args.step_games))
+    barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
+    for i in range(args.warmup):
+        t1 = time.time()
+        g, _ = step()
+        beat("warm-up step %d/%d: %d games in %.2f s" % (i + 1, args.warmup, g, time.time() - t1))
+    barrier()
+    c0 = counters()
+    t0 = time.time()
+    my_games, samples = 0, 0
+    for i in range(args.steps):
+        t1 = time.time()
+        g, samples = step()
+        my_games += g
+        beat("step %d/%d: %d games in %.2f s (%.1f games/s this rank, %.1f cumulative)"
+             % (i + 1, args.steps, g, time.time() - t1, g / max(time.time() - t1, 1e-9), my_games / (time.time() - t0)))
     barrier()
     dt = time.time() - t0
+    c1 = counters()
+    total_games = my_games
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_games = played[0]
-    assert total_games == args.games * args.waves * args.steps * world
+        t = torch.tensor([dt, float(my_games)], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, total_games = float(tmax[0].item()), int(round(float(t[1].item())))
+    stats = {k: c1[k] - c0.get(k, 0) for k in c1}
+
+    # ---- profiled step(s) outside the timed region: HIP-event spans of every trunk launch ------------------------
+    prof = {"evals": 0, "net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0, "union_ms": 0.0,
+            "wall_s": 0.0, "games": 0}
+    if args.profile_steps > 0:
+        for e_ in engs:
+            e_.set_timing(True)
+        for _ in range(args.profile_steps):
+            cp0 = counters()
+            t1 = time.time()
+            g, _ = step()
+            prof["wall_s"] += time.time() - t1
+            prof["games"] += g
+            cp1 = counters()
+            prof["evals"] += cp1["evals"] - cp0["evals"]
+            spans = []
+            for e_ in engs:
+                for k, v in e_.kernel_time().items():
+                    prof[k] += v
+                spans.append(e_.net_spans())
+            prof["union_ms"] += union_ms(spans)
+        for e_ in engs:
+            e_.set_timing(False)
+        beat("profiled step: %d games in %.2f s, %d trunk launches, busy %.0f ms"
+             % (prof["games"], prof["wall_s"], prof["net_launches"], prof["union_ms"]))
 
     if rank == 0:
-        traffic = None   # HBM-side bytes per k_trunk launch from the committed PMC profile (4096 positions)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_trunk_traffic.json")) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, traffic_file = None, None   # HBM-side bytes per k_trunk launch from the committed PMC profile (4096 positions)
+        for name in ("r02_trunk_traffic.json", "r01_trunk_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
+                traffic_file = name
+                break
+            except Exception:
+                pass
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
         # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
-        net_s = union_ms * 1e-3
-        flops = stats["evals"] * mflop_per_position(args.blocks, args.filters) * 1e6
+        net_s = prof["union_ms"] * 1e-3
+        flops = prof["evals"] * mflop_per_position(args.blocks, args.filters) * 1e6
         achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
         prec = ev.precision
         # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
         # source row is zero padding (1/12 of the conv work is skipped by the shipped kernel)
         issued = (3.0 if prec == "f16x3" else 1.0) * (11.0 / 12.0 if prec != "f32" else 1.0)
+        evals_per_game = stats["evals"] / max(1, stats["games"])
         out = {
             "metric": "self-play games/sec (8x8, 50 MCTS sims/move)",
             "value": round(total_games / dt, 3),
@@ -272,7 +346,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -282,42 +356,52 @@ def main():
             "config": {
                 "workload": "8x8, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank"
                             % (args.sims, args.blocks, args.filters, args.games),
-                "games_per_step_per_gpu": args.games * args.waves, "concurrent_games_per_gpu": args.games, "weights": "seeded random init (torch.manual_seed(42)), eval mode",
+                "step": "steady-state streaming: a step ends when >= %d more games per GPU have finished (slots stay "
+                        "full across steps; staggered start over %d ply rounds during warm-up)" % (args.step_games, args.stagger),
+                "games_timed": total_games, "concurrent_games_per_gpu": args.games,
+                "weights": "seeded random init (torch.manual_seed(42)), eval mode",
                 "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
                 "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
                                                             if world > 1 else "single GPU"),
                 "lanes_per_gpu": lanes,
-                "games_per_rank_last_step": ("equal" if world == 1 or args.equal_shares else
-                                             "proportional to each rank's measured rate in the previous step "
-                                             "(+-10 %% of equal, job total fixed): %s" % last_shares),
+                "step_targets_last_step": ("equal" if world == 1 or args.equal_shares else
+                                           "proportional to each rank's measured rate in the previous step "
+                                           "(+-10 %% of equal, job total fixed): %s" % list(shares)),
                 "eval_cache": ("off (every position the search reaches is evaluated by the network)" if not args.eval_cache
                                else "ON: 2^%d entries, %d hits -- NOT the headline configuration" % (args.eval_cache, stats["cache_hits"])),
                 "samples_last_step": samples,
-                "evals_per_game": round(stats["evals"] / max(1, stats["games"]), 1),
+                "evals_per_game": round(evals_per_game, 1),
                 "plies_per_game": round(stats["plies"] / max(1, stats["games"]), 2),
+                "timing_hooks_in_timed_region": False,
             },
             "roofline": {
                 "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                 "traffic_basis": "PMC FETCH_SIZE/WRITE_SIZE of a full launch of 4096 positions "
-                                 "(profiles/r01_trunk_traffic.json); algorithmic bytes of that launch: 1.18 MB",
+                                 "(profiles/%s); algorithmic bytes of that launch: 1.18 MB" % traffic_file,
+                "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"
+                               % (args.profile_steps, prof["games"], prof["wall_s"]),
                 "frac_mfma_issue": round(achieved * issued / PEAK_F16_TFLOPS, 4),
-                "launches": kt["net_launches"],
-                "avg_launch_ms": round(kt["net_ms"] / max(1, kt["net_launches"]), 4),
-                "busy_ms": round(union_ms, 1), "concurrent_lanes": lanes,
+                "launches": prof["net_launches"],
+                "avg_launch_ms": round(prof["net_ms"] / max(1, prof["net_launches"]), 4),
+                "busy_ms": round(prof["union_ms"], 1), "concurrent_lanes": lanes,
                 "time_basis": "union of the HIP-event intervals of all k_trunk launches (the %d lanes' launches "
-                              "overlap; sum of launch durations = %.0f ms)" % (lanes, kt["net_ms"]),
-                "positions_per_launch": round(stats["evals"] / max(1, kt["net_launches"]), 1),
+                              "overlap; sum of launch durations = %.0f ms)" % (lanes, prof["net_ms"]),
+                "positions_per_launch": round(prof["evals"] / max(1, prof["net_launches"]), 1),
                 "mfma_flops_issued_per_algorithmic_flop": round(issued, 3),
-                "net_time_share": round(net_s / (dt / max(1, 1)) if dt > 0 else 0.0, 4),
-                "tree_kernels_ms": round(kt["tree_ms"], 2),
+                "net_time_share": round(net_s / prof["wall_s"], 4) if prof["wall_s"] > 0 else None,
+                "tree_kernels_ms": round(prof["tree_ms"], 2), "tree_launches": prof["tree_launches"],
             },
+            "cpu_baseline": None,
         }
+        # evidence first: if the CPU leg were to be killed the measured line is already on stderr
+        print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget)
-        else:
-            out["cpu_baseline"] = None
+            try:
+                out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget, evals_per_game)
+            except Exception as exc:   # the GPU result must still be reported
+                out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()

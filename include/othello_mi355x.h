@@ -100,6 +100,11 @@ int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *o
 /* forward(x) for x float32 [n,3,8,8] holding 0/1 planes (the reference's input format) DEVICE */
 int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
 
+/* probs[i] = exp(logp[i]) exactly as the engine's expansion computes it from the network's log-probabilities
+ * (mcts.py:189 / parallel_self_play.py:72-76 `policy_probs = torch.exp(policy_logits)`): lets an external
+ * evaluator driven through oth_search_expand(is_log = 0) see the same float32 priors.  all DEVICE. */
+int oth_policy_exp(const float *logp, float *probs, int64_t n, void *stream);
+
 /* =============================================================================================
  * 4. Search + self-play engine
  *    replaces MCTS (src/mcts/mcts.py:17), MCTSNode (src/mcts/node.py:12), BatchMCTS
@@ -169,6 +174,27 @@ int oth_selfplay_search(oth_engine *e, float *pi, int32_t *active, void *stream)
 int oth_selfplay_apply(oth_engine *e, const int32_t *actions, int32_t *n_unfinished /*HOST*/, void *stream);
 /* finish a lock-step run: assign z and compact.  n_samples: HOST */
 int oth_selfplay_end(oth_engine *e, int64_t *n_samples, void *stream);
+/* ---- streaming self-play (steady state: the slots stay full ACROSS calls) ----------------------
+ * The reference's trainer calls execute_episodes(num_episodes) once per iteration (src/train/trainer.py:180-185)
+ * and each call starts from empty slots.  A stream keeps the max_games slots playing between calls: a step
+ * returns the games that FINISHED during it and leaves the others in flight, so there is no ragged tail per
+ * call.  Every game is still one complete self-play episode from the initial position with the same per-game
+ * arithmetic as oth_selfplay_run (random draws keyed by (seed, game id, ply), so a game's tuples depend on its id
+ * only, not on the slot or the step it lands in).
+ *   begin: all slots idle; slot g starts game id g at ply round g * stagger_rounds / max_games (0: all at once;
+ *          ~61 spreads the game phases evenly so that games finish at a steady rate), later games get ids
+ *          max_games, max_games+1, ... in the order slots free up.  hist_games = capacity of the history ring
+ *          (0: 8 * max_games); a step can return at most hist_games - 2 * max_games games.
+ *   step:  run ply rounds until at least min_games games have finished since the last step (checked one round
+ *          late so the device never idles: the step ends with the round after the one that reached the target),
+ *          then compact the tuples of ALL games finished so far, ascending game id.  Synchronous.  Read them with
+ *          oth_selfplay_fetch / oth_selfplay_device_ptrs; oth_selfplay_game_ids gives their ids.
+ * oth_engine_counters are cumulative over the stream. */
+int oth_stream_begin(oth_engine *e, uint64_t seed, int32_t stagger_rounds, int32_t hist_games, void *stream);
+int oth_stream_step(oth_engine *e, int32_t min_games, int32_t *n_games /*HOST*/, int64_t *n_samples /*HOST*/,
+                    void *stream);
+/* ids of the games whose tuples the last run / step produced, in output order.  ids: HOST [capacity] (may be NULL) */
+int oth_selfplay_game_ids(oth_engine *e, int32_t *ids, int32_t capacity, int32_t *count);
 /* Copy the replay tuples of the last run, game-major then ply order (the order of
  * parallel_self_play.py:400-405): states [n,3,8,8] f32, pis [n,65] f32, zs [n] f32,
  * game_len [num_games] int32 (may be NULL).  Destination pointers: ANY.  Synchronous. */

@@ -646,9 +646,80 @@ int64_t orc_selfplay_serial(const orc_selfplay_cfg *cfg, int num_episodes, orc_e
     return n;
 }
 
+/* ---- device-RNG restatement (the engine's default mode; no reference counterpart for the generator) --------
+ * The reference draws actions with numpy's global Mersenne-Twister stream (parallel_self_play.py:374-383,
+ * self_play.py:108-113), which serialises the games.  The HIP engine replaces the STREAM by a counter-based
+ * generator keyed by (seed, game id, ply) and keeps numpy's choice() arithmetic.  Restated here independently:
+ *   orc_philox4x32_10   Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as
+ *                       easy as 1, 2, 3", SC'11, and the Random123 library's philox.h): pinned by Random123's
+ *                       known-answer vectors in tests/test_oracle_golden.py;
+ *   orc_philox_uniform  key = seed (lo, hi), counter = (game id, ply, 0x2545F491, 0x9E3779B9); the double is
+ *                       built from the first two output words as numpy's random_sample does from two 32-bit
+ *                       draws: ((a >> 5) * 2^26 + (b >> 6)) / 2^53;
+ *   orc_choice_cdf      numpy.random.choice(65, p=pi) given its uniform draw u (numpy/random/mtrand.pyx, choice():
+ *                       cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(u, side='right')), p = pi as
+ *                       float64; pinned against numpy itself in tests/test_oracle_golden.py. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t x0 = ctr[0], x1 = ctr[1], x2 = ctr[2], x3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        if (round > 0) { /* bump the key between rounds (Weyl constants) */
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        uint64_t m0 = (uint64_t)0xD2511F53u * x0, m1 = (uint64_t)0xCD9E8D57u * x2;
+        uint32_t n0 = (uint32_t)(m1 >> 32) ^ x1 ^ k0, n1 = (uint32_t)m1;
+        uint32_t n2 = (uint32_t)(m0 >> 32) ^ x3 ^ k1, n3 = (uint32_t)m0;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+    }
+    out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+}
+double orc_philox_uniform(uint64_t seed, uint32_t game_id, uint32_t ply) {
+    const uint32_t ctr[4] = {game_id, ply, 0x2545F491u, 0x9E3779B9u};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    orc_philox4x32_10(ctr, key, o);
+    return ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
+}
+int orc_choice_cdf(const float *pi65, double u) {
+    double cdf[65], c = 0.0;
+    for (int i = 0; i < 65; ++i) { /* np.cumsum of the float64 copy of p: sequential adds */
+        c += (double)pi65[i];
+        cdf[i] = c;
+    }
+    const double last = cdf[64];
+    int idx = 0; /* searchsorted(u, side='right') = number of entries <= u */
+    while (idx < 65 && cdf[idx] / last <= u) ++idx;
+    return idx;
+}
+
+static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episodes, orc_eval_fn eval, void *ectx,
+                                      const orc_rng *rng, int use_philox, uint64_t philox_seed, int late_onehot,
+                                      int64_t cap, float *states, float *pis, float *zs, int32_t *moves,
+                                      int32_t *game_len);
+
 int64_t orc_selfplay_parallel(const orc_selfplay_cfg *cfg, int num_episodes, orc_eval_fn eval, void *ectx,
                               const orc_rng *rng, int64_t cap, float *states, float *pis, float *zs,
                               int32_t *moves) {
+    return selfplay_parallel_impl(cfg, num_episodes, eval, ectx, rng, 0, 0, 0, cap, states, pis, zs, moves, NULL);
+}
+/* oth_selfplay_run / oth_stream_* semantics: game g (0-based id) is an independent episode played as
+ * ParallelSelfPlayWorker plays it (parallel_self_play.py:324-407: search at T=1, pi = visit distribution, sample
+ * while ply < threshold else argmax) with the ply-p action drawn from orc_philox_uniform(seed, g, p).  Output:
+ * game-major in id order; game_len[g] (may be NULL).  late_onehot = 1: the stored pi of a ply at or after the
+ * threshold is the one-hot of the arg-max, as SelfPlayWorker stores it (self_play.py:87-105: the search result at
+ * temperature 0, node.py:165-170).  Games are evaluated in lock-step batches of
+ * cfg->num_parallel_games only to batch the evaluator calls; no game's tuples depend on the batching. */
+int64_t orc_selfplay_philox(const orc_selfplay_cfg *cfg, int num_games, uint64_t seed, int late_onehot,
+                            orc_eval_fn eval, void *ectx, int64_t cap, float *states, float *pis, float *zs,
+                            int32_t *moves, int32_t *game_len) {
+    return selfplay_parallel_impl(cfg, num_games, eval, ectx, NULL, 1, seed, late_onehot, cap, states, pis, zs, moves,
+                                  game_len);
+}
+
+static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episodes, orc_eval_fn eval, void *ectx,
+                                      const orc_rng *rng, int use_philox, uint64_t philox_seed, int late_onehot,
+                                      int64_t cap, float *states, float *pis, float *zs, int32_t *moves,
+                                      int32_t *game_len) {
     orc_rng lr;
     xo_state st;
     if (!rng || !rng->dirichlet) {
@@ -686,9 +757,17 @@ int64_t orc_selfplay_parallel(const orc_selfplay_cfg *cfg, int num_episodes, orc
                 int i = aidx[j];
                 if (mc[i] >= MAXP) return -1;
                 double temp = mc[i] < cfg->temperature_threshold ? 1.0 : 0.0;
-                int a = temp == 0 ? argmax65(api + 65 * j) : rng->choice(rng->ctx, api + 65 * j);
+                int a;
+                if (temp == 0) a = argmax65(api + 65 * j);
+                else if (use_philox)
+                    a = orc_choice_cdf(api + 65 * j, orc_philox_uniform(philox_seed, (uint32_t)(completed + i), (uint32_t)mc[i]));
+                else a = rng->choice(rng->ctx, api + 65 * j);
                 orc_tensor(&bd[i], hs + ((int64_t)i * MAXP + mc[i]) * 192);
                 memcpy(hp + ((int64_t)i * MAXP + mc[i]) * 65, api + 65 * j, sizeof(float) * 65);
+                if (late_onehot && temp == 0) {
+                    float *row = hp + ((int64_t)i * MAXP + mc[i]) * 65;
+                    for (int k = 0; k < 65; ++k) row[k] = k == a ? 1.0f : 0.0f;
+                }
                 hpl[i * MAXP + mc[i]] = (mc[i] % 2 == 0) ? 1 : -1;
                 hmv[i * MAXP + mc[i]] = a;
                 orc_make_move(&bd[i], a);
@@ -700,6 +779,8 @@ int64_t orc_selfplay_parallel(const orc_selfplay_cfg *cfg, int num_episodes, orc
             }
         }
         for (int i = 0; i < bs; ++i) /* :400-405 game-major */
+            if (game_len) game_len[completed + i] = mc[i];
+        for (int i = 0; i < bs; ++i)
             for (int p = 0; p < mc[i]; ++p) {
                 if (n >= cap) return -1;
                 memcpy(states + n * 192, hs + ((int64_t)i * MAXP + p) * 192, sizeof(float) * 192);
@@ -942,5 +1023,59 @@ int64_t orc_cpu_baseline(const orc_net *net, const orc_selfplay_cfg *cfg, int st
     }
     if (n_evals) *n_evals = evals;
     if (threads_used) *threads_used = nt;
+    return total;
+}
+
+/* Phase-uniform CPU baseline: stream s first plays (s * spread) / streams plies with uniformly random legal
+ * moves (untimed by the caller's clock only in the sense that no search runs: it costs microseconds), then
+ * `plies_per_stream` plies of real serial self-play (self_play.py:80-117: search, record, sample/argmax, move),
+ * starting a fresh game whenever one ends.  With spread ~ one game length the sample covers openings, middle
+ * games and endgames (terminal leaves included) in the proportions a whole game has. */
+int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int plies_per_stream,
+                                int spread, uint64_t seed, int64_t *n_evals, int *threads_used, int64_t *games_ended) {
+    int64_t total = 0, evals = 0, ended = 0;
+    int nt = 1;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nt = omp_get_num_threads();
+#endif
+#pragma omp for schedule(dynamic, 1) reduction(+ : total, evals, ended)
+        for (int s = 0; s < streams; ++s) {
+            xo_state st;
+            orc_rng r;
+            default_rng(&r, &st, seed + 1000003ULL * (uint64_t)s);
+            count_ctx cc = {net, 0};
+            orc_board b;
+            orc_reset(&b);
+            int skip = spread > 0 ? (int)(((int64_t)s * spread) / streams) : 0;
+            for (int i = 0; i < skip && !orc_is_terminal(&b); ++i) {
+                int mv[65];
+                int n = orc_legal_list(&b, mv);
+                orc_make_move(&b, mv[(int)(xo_uniform(&st) * n) % n]);
+            }
+            float pi[65];
+            for (int done = 0; done < plies_per_stream;) {
+                if (orc_is_terminal(&b)) {
+                    orc_reset(&b);
+                    ended += 1;
+                    continue;
+                }
+                double temp = b.move_count < cfg->temperature_threshold ? 1.0 : 0.0;
+                orc_search_cfg sc = {cfg->num_simulations, cfg->c_puct, cfg->dirichlet_alpha, cfg->dirichlet_epsilon,
+                                     temp, cfg->add_noise};
+                orc_search(&b, &sc, counting_eval, &cc, &r, pi, NULL, NULL, NULL);
+                int a = temp == 0 ? argmax65(pi) : r.choice(r.ctx, pi);
+                orc_make_move(&b, a);
+                ++done;
+                ++total;
+            }
+            evals += cc.evals;
+        }
+    }
+    if (n_evals) *n_evals = evals;
+    if (threads_used) *threads_used = nt;
+    if (games_ended) *games_ended = ended;
     return total;
 }

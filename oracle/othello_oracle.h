@@ -95,6 +95,18 @@ int64_t orc_selfplay_parallel(const orc_selfplay_cfg *cfg, int num_episodes, orc
                               void *eval_ctx, const orc_rng *rng, int64_t cap, float *states,
                               float *pis, float *zs, int32_t *moves);
 
+/* ---- device-RNG self-play (the HIP engine's default mode) -------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11 / Random123 philox.h; pinned by Random123's known-answer vectors),
+ * the engine's keying (seed; game id, ply) and numpy's choice() arithmetic given the uniform draw (pinned
+ * against numpy.random.RandomState.choice).  orc_selfplay_philox: every game id an independent
+ * ParallelSelfPlayWorker-style episode (parallel_self_play.py:324-407), tuples game-major in id order. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_philox_uniform(uint64_t seed, uint32_t game_id, uint32_t ply);
+int orc_choice_cdf(const float *pi65, double u);
+int64_t orc_selfplay_philox(const orc_selfplay_cfg *cfg, int num_games, uint64_t seed, int late_onehot,
+                            orc_eval_fn eval, void *eval_ctx, int64_t cap, float *states, float *pis, float *zs,
+                            int32_t *moves, int32_t *game_len);
+
 /* ---- CPU network: src/model/net.py:139-205 (eval mode, fp32) -------------------------------- */
 typedef struct orc_net orc_net;
 /* blob = state_dict tensors in registration order, float32, int64 num_batches_tracked skipped:
@@ -111,6 +123,11 @@ void orc_net_eval(void *ctx, int n, const uint64_t *self_b, const uint64_t *opp_
  * playing `plies_per_stream` plies (bounded sample).  Returns total plies played; evals counted. */
 int64_t orc_cpu_baseline(const orc_net *net, const orc_selfplay_cfg *cfg, int streams,
                          int plies_per_stream, uint64_t seed, int64_t *n_evals, int *threads_used);
+
+/* same, phase-uniform: stream s starts (s * spread) / streams random plies into a game, so the sample covers
+ * openings, middle games and endgames like a whole game does; a stream starts a new game when one ends. */
+int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int plies_per_stream,
+                                int spread, uint64_t seed, int64_t *n_evals, int *threads_used, int64_t *games_ended);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ _SIGS = {
     "oth_net_load_state": (C.c_int, [vp, f32p, C.c_int64, C.c_int]),
     "oth_net_forward_bits": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
     "oth_net_forward_planes": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
+    "oth_policy_exp": (C.c_int, [vp, vp, C.c_int64, vp]),
     "oth_engine_create": (vp, [C.POINTER(EngineCfg)]),
     "oth_engine_destroy": (None, [vp]),
     "oth_engine_set_net": (C.c_int, [vp, vp]),
@@ -76,6 +77,9 @@ _SIGS = {
     "oth_selfplay_search": (C.c_int, [vp, f32p, i32p, vp]),
     "oth_selfplay_apply": (C.c_int, [vp, i32p, i32p, vp]),
     "oth_selfplay_end": (C.c_int, [vp, i64p, vp]),
+    "oth_stream_begin": (C.c_int, [vp, C.c_uint64, C.c_int32, C.c_int32, vp]),
+    "oth_stream_step": (C.c_int, [vp, C.c_int32, i32p, i64p, vp]),
+    "oth_selfplay_game_ids": (C.c_int, [vp, i32p, C.c_int32, i32p]),
     "oth_selfplay_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "oth_selfplay_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]),
     "oth_engine_counters": (C.c_int, [vp, i64p]),

@@ -8,11 +8,19 @@
 // enough to stay L2/Infinity-Cache resident.  Leaves are appended to a dense evaluation batch
 // (24 B per position: self, opp, legal) that the network kernel consumes without a host round trip.
 //
+// ONE tree kernel per simulation (k_tree): expand the leaf evaluated by the previous network launch
+// and back its value up (node.py:62-89, mcts.py:152-168), then -- same wave, same launch -- select the
+// next leaf (node.py:91-126) or, after the last simulation, finish the ply (pi, move, end of game,
+// slot refill, next root).  The evaluation-batch cursor is double-buffered (the launch that fills one
+// counter zeroes the other), so a simulation costs exactly two launches: k_tree and the network.
+//
 // Reference semantics reproduced: L8 expand, L9 select, L10 backup incl. the root
 // never being backed up, L11 terminal leaves, L13 policy from visit counts, L14-L18 worker loops.
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -38,6 +46,10 @@ struct __attribute__((aligned(16))) Edge {  // 16 B: one 128-bit load per lane
 };
 
 enum : int32_t { PEND_NONE = 0, PEND_ROOT = 1, PEND_LEAF = 2 };
+enum : int { TREE_NONE = 0, TREE_SELECT = 1, TREE_PLY = 2 };       // what k_tree does after the expansion
+enum : int { ST_ACTIVE = 0, ST_DONE = 1, ST_FLAGS = 2, ST_NEXT = 3 };  // words of Dev::status
+enum : int32_t { FLAG_HIST_OVERFLOW = 1 };
+constexpr int kCachedSlot = -2;  // eval_slot value: the result row is in Dev::cres[g] (evaluation-cache hit)
 
 struct Dev {  // device pointers + scalars handed to every kernel by value
     int32_t n_slots, cap_nodes, cap_edges, cap_path, num_sims, temp_threshold, store_late_onehot;
@@ -45,29 +57,34 @@ struct Dev {  // device pointers + scalars handed to every kernel by value
     // per slot
     uint64_t *g_self, *g_opp;        // current game position
     int32_t *g_ply, *g_id, *g_active;  // ply counter, game id, slot searching this step
+    int32_t* g_join;                 // round at which an idle slot starts its first game (-1: never)
     Node* nodes;
     Edge* edges;
     int32_t *n_nodes, *n_edges;
     uint32_t* path;
     int32_t *path_len, *pend, *eval_slot;
     uint64_t *leaf_self, *leaf_opp, *leaf_legal;
-    // evaluation batch (dense, filled through an atomic cursor)
+    // evaluation batch (dense, filled through an atomic cursor; the cursor is double-buffered)
     uint64_t *ev_self, *ev_opp, *ev_legal;
-    int32_t* n_eval;
+    int32_t *n_eval, *n_eval_next;   // cursor of THIS launch, cursor of the next one (zeroed by this launch)
     float *logp, *val;
     const double* sqrt_tab;  // sqrt(n) exactly as numpy computes it, n = 0..num_sims+1
     // self-play bookkeeping
-    int32_t *next_game, *n_active, num_games;
-    uint64_t* hist_bits;   // [num_games][kMaxPly][3]
-    float* hist_pi;        // [num_games][kMaxPly][65]
-    int32_t *game_len, *game_winner;
+    int32_t* status;         // [ST_ACTIVE] playing slots, [ST_DONE] finished games, [ST_FLAGS], [ST_NEXT] next game id
+    int32_t game_limit;      // ids >= game_limit are not started
+    int32_t hist_mask;       // history ring: game id & hist_mask
+    int32_t round;           // ply round of this launch (0 = initial joins)
+    uint64_t* hist_bits;     // [hist_cap][kMaxPly][3]
+    float* hist_pi;          // [hist_cap][kMaxPly][65]
+    int32_t *game_len, *game_winner;  // [hist_cap]; game_len: -1 free, 0 in progress, >0 finished (plies)
+    int32_t* done_list;      // [hist_cap] ring of finished game ids in completion order
     unsigned long long* counters;  // [blocks][8]
     uint64_t seed;
     // optional evaluation cache (transposition table of network outputs), direct-mapped
     uint64_t* ck;       // [C][2] keys (self, opp); all-ones = empty
     float* cv;          // [C][66] raw policy (65) + value
     int32_t* clk;       // [C] claim epoch of the last insert
-    int32_t* ins;       // [n_slots] 1 = this game's pending position was evaluated by the network this step
+    float* cres;        // [n_slots][66] result row copied at lookup time (an insert may replace the entry later)
     uint32_t cmask;     // C - 1, 0 = cache disabled
     int32_t cepoch;
 };
@@ -154,10 +171,17 @@ __device__ __forceinline__ uint32_t cache_slot(const Dev& d, uint64_t sb, uint64
     h = (h ^ (h >> 27)) * 0x94D049BB133111EBULL;
     return (uint32_t)(h ^ (h >> 31)) & d.cmask;
 }
-__device__ __forceinline__ int cache_lookup(const Dev& d, uint64_t sb, uint64_t ob) {
-    if (d.cmask == 0) return -1;
+// On a hit the 66-float result row is copied into the game's own row cres[g] right away: the entry may be
+// replaced by an insert before the expansion (next launch) reads it.  Whole wave calls; returns hit or not.
+__device__ __forceinline__ bool cache_fetch(const Dev& d, int g, uint64_t sb, uint64_t ob, int lane) {
+    if (d.cmask == 0) return false;
     const uint32_t cs = cache_slot(d, sb, ob);
-    return (d.ck[2 * (size_t)cs] == sb && d.ck[2 * (size_t)cs + 1] == ob) ? (int)cs : -1;
+    if (!(d.ck[2 * (size_t)cs] == sb && d.ck[2 * (size_t)cs + 1] == ob)) return false;
+    const float* src = d.cv + (size_t)cs * 66;
+    float* dst = d.cres + (size_t)g * 66;
+    dst[lane] = src[lane];
+    if (lane < 2) dst[64 + lane] = src[64 + lane];
+    return true;
 }
 
 __device__ __forceinline__ void write_eval(const Dev& d, int slot, uint64_t sb, uint64_t ob, uint64_t lg, int lane) {
@@ -168,88 +192,14 @@ __device__ __forceinline__ void write_eval(const Dev& d, int slot, uint64_t sb, 
     }
 }
 
-// ---- K1a: select (node.py:91-126, parallel_self_play.py:172-197) ----------------------------------
-__global__ __launch_bounds__(256) void k_select(Dev d) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    extern __shared__ uint32_t lds_path_all[];  // [4 waves][cap_path]: the path of the current descent
-    __shared__ BlockTally bt;
-    volatile uint32_t* lpath = lds_path_all + (threadIdx.x >> 6) * d.cap_path;
-    const bool live = g < d.n_slots && d.g_active[g];
-    bool need = false, terminal = false;
-    uint64_t sb = 0, ob = 0, lg = 0;
-    int depth = 0, cached = -1;
-    Edge* edges = nullptr;
-    uint32_t* path = nullptr;
-    if (live) {
-        Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
-        edges = d.edges + (size_t)g * d.cap_edges;
-        path = d.path + (size_t)g * d.cap_path;
-        int node = 0, pv = 0;
-        sb = nodes[0].self_b;
-        ob = nodes[0].opp_b;
-        for (;;) {
-            const Node nd = nodes[node];
-            const bool pass = nd.legal == 0;
-            const bool act = pass ? (lane == 0) : ((nd.legal >> lane) & 1ULL);
-            const int rank = __popcll(nd.legal & ((1ULL << lane) - 1ULL));
-            const int ei = (int)nd.edge_base + rank;
-            double score = -INFINITY;
-            int e_n = 0, e_child = 0;
-            if (act) {
-                const Edge e = edges[ei];
-                e_n = e.n;
-                e_child = e.child;
-                const double q = e.n == 0 ? 0.0 : e.w / (double)e.n;          // node.py:51-60
-                const float cp_p = d.c_puct * e.prior;                       // float32 product (weak python scalar)
-                const double u = (double)cp_p * d.sqrt_tab[pv] / (double)(1 + e.n);  // node.py:116
-                score = q + u;                                               // node.py:119
-            }
-            const double best = wave_max_f64(score);
-            const unsigned long long eq = __ballot(act && score == best);
-            const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
-            const int action = pass ? 64 : L;
-            const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
-            if (lane == 0) lpath[depth] = (uint32_t)ce;
-            ++depth;
-            apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
-            if (child == 0) break;        // that child has no children yet: leaf
-            pv = nvis;
-            node = child;
-        }
-        lg = legal_moves(sb, ob);
-        terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
-        if (!terminal) cached = cache_lookup(d, sb, ob);
-        need = !terminal && cached < 0;
-    }
-    int slot = block_alloc_eval(d, bt, need, live ? 1 : 0, terminal ? 1 : 0, 0, 0, cached >= 0 ? 1 : 0);
-    if (!live) return;
-    if (cached >= 0) slot = -(cached + 2);  // negative: read the result from cache entry `cached`
-    if (terminal) {  // parallel_self_play.py:133-135: back up float(get_winner()) immediately
-        backup_path(edges, lpath, depth, (double)winner(sb, ob), lane, 0);
-        if (lane == 0) d.pend[g] = PEND_NONE;
-    } else {
-        if (slot >= 0) write_eval(d, slot, sb, ob, lg, lane);
-        for (int i = lane; i < depth; i += 64) path[i] = lpath[i];  // for k_expand (next launch)
-        if (lane == 0) {
-            d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
-            d.path_len[g] = depth;
-            d.eval_slot[g] = slot;
-            d.pend[g] = PEND_LEAF;
-        }
-    }
-}
-
-// ---- K1b: expand + backup (node.py:62-89, mcts.py:133-148) ---------------------------------------
-__global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__ policy,
-                                                const float* __restrict__ value, int is_log) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= d.n_slots) return;
-    const int pend = d.pend[g];
-    if (pend == PEND_NONE) return;
+// ---- expand + backup (node.py:62-89, mcts.py:133-148) ---------------------------------------------
+// The pending position of game g (its root, or the leaf chosen by the previous launch) has been evaluated:
+// mask + renormalise the priors, append the node and its edges, link it and back the value up.
+__device__ __forceinline__ void expand_pending(const Dev& d, int g, int lane, int pend,
+                                               const float* __restrict__ policy, const float* __restrict__ value,
+                                               int is_log) {
     const int slot = d.eval_slot[g];
-    const float* pol = slot >= 0 ? policy + (size_t)slot * 65 : d.cv + (size_t)(-slot - 2) * 66;
+    const float* pol = slot >= 0 ? policy + (size_t)slot * 65 : d.cres + (size_t)g * 66;
     const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g], legal = d.leaf_legal[g];
     const bool pass = legal == 0;
     float p = pol[lane], p64 = pol[64];
@@ -293,7 +243,6 @@ __global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__
         d.n_nodes[g] = id + 1;
         d.n_edges[g] = base + nch;
         d.pend[g] = PEND_NONE;
-        if (d.cmask) d.ins[g] = slot >= 0 ? 1 : 0;
     }
     if (depth > 0) {
         const double v = (double)(slot >= 0 ? value[slot] : pol[65]);  // values[j].item(): float32 -> python float
@@ -301,19 +250,19 @@ __global__ __launch_bounds__(256) void k_expand(Dev d, const float* __restrict__
     }
 }
 
+// Insert the fresh network results of the pending positions into the evaluation cache.  Runs as its own
+// launch between the network and k_tree, so no entry is read (cache_fetch, in k_tree) while it is rewritten.
 __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __restrict__ policy,
                                                       const float* __restrict__ value) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= d.n_slots || !d.ins[g]) return;
-    const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g];
+    if (g >= d.n_slots || d.pend[g] == PEND_NONE) return;
     const int slot = d.eval_slot[g];
+    if (slot < 0) return;
+    const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g];
     const uint32_t cs = cache_slot(d, sb, ob);
     int own = 0;
-    if (lane == 0) {
-        own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
-        d.ins[g] = 0;
-    }
+    if (lane == 0) own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
     if (!__shfl(own, 0)) return;
     float* dst = d.cv + (size_t)cs * 66;
     dst[lane] = policy[(size_t)slot * 65 + lane];
@@ -325,7 +274,8 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
     }
 }
 
-// Philox4x32-10 keyed by (seed), counter (game id, ply): one uniform double in [0,1) per decision
+// Philox4x32-10 keyed by (seed), counter (game id, ply, 0x2545F491, 0x9E3779B9): one uniform double in [0,1)
+// per decision (restated in oracle/othello_oracle.c orc_philox_uniform; the two are compared bit for bit)
 __device__ inline double philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     uint32_t x0 = c0, x1 = c1, x2 = 0x2545F491u, x3 = 0x9E3779B9u;
@@ -360,12 +310,13 @@ __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __r
     __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d.n_eval_next = 0;
     const bool live = g < n;
     uint64_t s0 = 0, o0 = 0;
-    int cached = -1;
-    if (live) { s0 = sb[g]; o0 = ob[g]; cached = cache_lookup(d, s0, o0); }
-    int slot = block_alloc_eval(d, bt, live && cached < 0, 0, 0, 0, 0, cached >= 0 ? 1 : 0);
-    if (cached >= 0) slot = -(cached + 2);
+    bool cached = false;
+    if (live) { s0 = sb[g]; o0 = ob[g]; cached = cache_fetch(d, g, s0, o0, lane); }
+    int slot = block_alloc_eval(d, bt, live && !cached, 0, 0, 0, 0, cached ? 1 : 0);
+    if (cached) slot = kCachedSlot;
     if (g >= d.n_slots) return;
     if (!live) {
         if (lane == 0) { d.g_active[g] = 0; d.pend[g] = PEND_NONE; }
@@ -375,133 +326,223 @@ __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __r
     begin_root(d, g, s0, o0, legal_moves(s0, o0), slot, lane);
 }
 
-// start games: slot g gets game id g (or stays idle), ply 0, start position, root queued
-__global__ __launch_bounds__(256) void k_games_begin(Dev d, int n_start) {
-    __shared__ BlockTally bt;
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool live = g < n_start;
-    const int cached = live ? cache_lookup(d, kStartSelf, kStartOpp) : -1;
-    int slot = block_alloc_eval(d, bt, live && cached < 0, 0, 0, 0, 0, cached >= 0 ? 1 : 0);
-    if (cached >= 0) slot = -(cached + 2);
+// all slots idle; slot g < n_start joins (starts game id g) at round g * stagger / n_start (stagger 0: at once)
+__global__ void k_slots_init(Dev d, int n_start, int stagger) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.n_slots) return;
-    if (!live) {
-        if (lane == 0) { d.g_active[g] = 0; d.g_id[g] = -1; d.pend[g] = PEND_NONE; }
-        return;
-    }
-    if (lane == 0) {
-        d.g_active[g] = 1; d.g_id[g] = g; d.g_ply[g] = 0;
-        d.g_self[g] = kStartSelf; d.g_opp[g] = kStartOpp;
-        atomicAdd(d.n_active, 1);
-    }
-    begin_root(d, g, kStartSelf, kStartOpp, legal_moves(kStartSelf, kStartOpp), slot, lane);
+    d.g_active[g] = 0;
+    d.g_id[g] = -1;
+    d.pend[g] = PEND_NONE;
+    d.g_join[g] = g < n_start ? (int)(((long long)g * stagger) / n_start) : -1;
 }
 
-// ---- K4: ply step (node.py:147-182, parallel_self_play.py:374-397, self_play.py:101-117) ---------
-// Per game: pi from root visit counts, record (position, pi), choose the action (sample while
-// ply < threshold, else first argmax), play it, detect the end of the game, refill the slot, and
-// queue the next root.  forced != nullptr: play forced[g] instead (host-driven lock-step mode).
-__global__ __launch_bounds__(256) void k_ply(Dev d, const int32_t* __restrict__ forced, int refill) {
+// ---- the tree kernel ------------------------------------------------------------------------------
+// Phase A (every mode): expand_pending for games whose pending position has been evaluated.
+// Phase B: TREE_SELECT  one descent (node.py:91-126, parallel_self_play.py:172-197): the leaf is backed up at
+//                       once when terminal (mcts.py:127-130), else queued for the network;
+//          TREE_PLY     the ply step (node.py:147-182, parallel_self_play.py:374-397, self_play.py:101-117):
+//                       pi from the root visit counts, record (position, pi), choose the action (sample while
+//                       ply < threshold, else first argmax; forced != nullptr: play forced[g]), play it, detect
+//                       the end of the game, refill the slot, queue the next root; idle slots whose join round
+//                       has come start their first game;
+//          TREE_NONE    nothing (last launch of a stand-alone search).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ policy, const float* __restrict__ value,
+                                              int is_log, const int32_t* __restrict__ forced, int refill) {
+    extern __shared__ uint32_t lds_path_all[];  // [4 waves][cap_path]: the path of the current descent
     __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool live = g < d.n_slots && d.g_active[g];
-    bool next_root = false, over = false;
-    uint64_t sb = 0, ob = 0;
-    int nply = 0, gid = -1;
-    if (live) {
-        const Node root = d.nodes[(size_t)g * d.cap_nodes];
-        const Edge* edges = d.edges + (size_t)g * d.cap_edges;
-        const bool pass = root.legal == 0;
-        const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
-        const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
-        const int n = act ? (int)edges[root.edge_base + rank].n : 0;
-        const int n64 = pass ? (int)edges[root.edge_base].n : 0;
-        const int total = wave_sum_i32(n) + n64;
-        // counts / counts.sum() in float32 (node.py:175-177 with temperature 1)
-        const float tot_f = (float)total;
-        float pi = act ? (float)n / tot_f : 0.0f;
-        float pi64 = pass ? (float)n64 / tot_f : 0.0f;
-        // first maximum of the visit counts (np.argmax)
-        const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
-        const unsigned long long eqm = __ballot(act && n == best_n);
-        const int amax = pass ? 64 : (__ffsll(eqm) - 1);
-        const int ply = d.g_ply[g];
-        gid = d.g_id[g];
-        const bool sample = ply < d.temp_threshold;
-        int action;
-        if (forced) {
-            action = forced[g];
-        } else if (!sample) {
-            action = amax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d.n_eval_next = 0;
+    const bool in_range = g < d.n_slots;
+    {
+        const int pend = in_range ? d.pend[g] : PEND_NONE;
+        if (pend != PEND_NONE) expand_pending(d, g, lane, pend, policy, value, is_log);
+    }
+    if constexpr (MODE == TREE_NONE) return;
+    // the descent / the ply step below read nodes and edges other lanes of this wave have just written
+    __threadfence_block();
+    const bool live = in_range && d.g_active[g];
+
+    if constexpr (MODE == TREE_SELECT) {
+        volatile uint32_t* lpath = lds_path_all + (threadIdx.x >> 6) * d.cap_path;
+        bool need = false, terminal = false, cached = false;
+        uint64_t sb = 0, ob = 0, lg = 0;
+        int depth = 0;
+        Edge* edges = nullptr;
+        uint32_t* path = nullptr;
+        if (live) {
+            Node* nodes = d.nodes + (size_t)g * d.cap_nodes;
+            edges = d.edges + (size_t)g * d.cap_edges;
+            path = d.path + (size_t)g * d.cap_path;
+            int node = 0, pv = 0;
+            sb = nodes[0].self_b;
+            ob = nodes[0].opp_b;
+            for (;;) {
+                const Node nd = nodes[node];
+                const bool pass = nd.legal == 0;
+                const bool act = pass ? (lane == 0) : ((nd.legal >> lane) & 1ULL);
+                const int rank = __popcll(nd.legal & ((1ULL << lane) - 1ULL));
+                const int ei = (int)nd.edge_base + rank;
+                double score = -INFINITY;
+                int e_n = 0, e_child = 0;
+                if (act) {
+                    const Edge e = edges[ei];
+                    e_n = e.n;
+                    e_child = e.child;
+                    const double q = e.n == 0 ? 0.0 : e.w / (double)e.n;          // node.py:51-60
+                    const float cp_p = d.c_puct * e.prior;                       // float32 product (weak python scalar)
+                    const double u = (double)cp_p * d.sqrt_tab[pv] / (double)(1 + e.n);  // node.py:116
+                    score = q + u;                                               // node.py:119
+                }
+                const double best = wave_max_f64(score);
+                const unsigned long long eq = __ballot(act && score == best);
+                const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
+                const int action = pass ? 64 : L;
+                const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
+                if (lane == 0) lpath[depth] = (uint32_t)ce;
+                ++depth;
+                apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
+                if (child == 0) break;        // that child has no children yet: leaf
+                pv = nvis;
+                node = child;
+            }
+            lg = legal_moves(sb, ob);
+            terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
+            if (!terminal) cached = cache_fetch(d, g, sb, ob, lane);
+            need = !terminal && !cached;
+        }
+        int slot = block_alloc_eval(d, bt, need, live ? 1 : 0, terminal ? 1 : 0, 0, 0, cached ? 1 : 0);
+        if (!live) return;
+        if (cached) slot = kCachedSlot;
+        if (terminal) {  // parallel_self_play.py:133-135: back up float(get_winner()) immediately
+            backup_path(edges, lpath, depth, (double)winner(sb, ob), lane, 0);
+            if (lane == 0) d.pend[g] = PEND_NONE;
         } else {
-            // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
-            const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
-            double c = 0.0;
-            double cdf_lane = 0.0;
-            for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
-                c += (double)__shfl(pi, i);
-                if (i == lane) cdf_lane = c;
-            }
-            const double c64 = c + (double)pi64;
-            const unsigned long long gt = __ballot(cdf_lane / c64 > u);
-            action = gt ? (__ffsll(gt) - 1) : 64;
-        }
-        if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
-            pi = (lane == amax) ? 1.0f : 0.0f;
-            pi64 = (amax == 64) ? 1.0f : 0.0f;
-        }
-        // record the sample: position bits (state planes are unpacked at compaction) and pi
-        sb = d.g_self[g];
-        ob = d.g_opp[g];
-        {
-            const size_t h = (size_t)gid * kMaxPly + ply;
-            float* hp = d.hist_pi + h * 65;
-            hp[lane] = pi;
+            if (slot >= 0) write_eval(d, slot, sb, ob, lg, lane);
+            for (int i = lane; i < depth; i += 64) path[i] = lpath[i];  // for the expansion (next launch)
             if (lane == 0) {
-                hp[64] = pi64;
-                d.hist_bits[h * 3 + 0] = sb;
-                d.hist_bits[h * 3 + 1] = ob;
-                d.hist_bits[h * 3 + 2] = root.legal;
+                d.leaf_self[g] = sb; d.leaf_opp[g] = ob; d.leaf_legal[g] = lg;
+                d.path_len[g] = depth;
+                d.eval_slot[g] = slot;
+                d.pend[g] = PEND_LEAF;
             }
         }
-        apply_known(sb, ob, action);  // game.board.make_move(action)
-        nply = ply + 1;
-        over = is_terminal(sb, ob) || nply >= kMaxPly;
-        if (over) {
-            int new_id = -1;
-            if (lane == 0) {
-                d.game_len[gid] = nply;
-                d.game_winner[gid] = winner(sb, ob);  // relative to the side to move at the end (L16)
-                if (refill) {
-                    const int nid = atomicAdd(d.next_game, 1);
-                    if (nid < d.num_games) new_id = nid;
+    } else {  // TREE_PLY
+        bool next_root = false, over = false, joined = false;
+        uint64_t sb = 0, ob = 0;
+        int nply = 0, gid = -1;
+        if (live) {
+            const Node root = d.nodes[(size_t)g * d.cap_nodes];
+            const Edge* edges = d.edges + (size_t)g * d.cap_edges;
+            const bool pass = root.legal == 0;
+            const bool act = pass ? false : ((root.legal >> lane) & 1ULL);
+            const int rank = __popcll(root.legal & ((1ULL << lane) - 1ULL));
+            const int n = act ? (int)edges[root.edge_base + rank].n : 0;
+            const int n64 = pass ? (int)edges[root.edge_base].n : 0;
+            const int total = wave_sum_i32(n) + n64;
+            // counts / counts.sum() in float32 (node.py:175-177 with temperature 1)
+            const float tot_f = (float)total;
+            float pi = act ? (float)n / tot_f : 0.0f;
+            float pi64 = pass ? (float)n64 / tot_f : 0.0f;
+            // first maximum of the visit counts (np.argmax)
+            const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
+            const unsigned long long eqm = __ballot(act && n == best_n);
+            const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+            const int ply = d.g_ply[g];
+            gid = d.g_id[g];
+            const bool sample = ply < d.temp_threshold;
+            int action;
+            if (forced) {
+                action = forced[g];
+            } else if (!sample) {
+                action = amax;
+            } else {
+                // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
+                const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
+                double c = 0.0;
+                double cdf_lane = 0.0;
+                for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
+                    c += (double)__shfl(pi, i);
+                    if (i == lane) cdf_lane = c;
+                }
+                const double c64 = c + (double)pi64;
+                const unsigned long long gt = __ballot(cdf_lane / c64 > u);
+                action = gt ? (__ffsll(gt) - 1) : 64;
+            }
+            if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
+                pi = (lane == amax) ? 1.0f : 0.0f;
+                pi64 = (amax == 64) ? 1.0f : 0.0f;
+            }
+            // record the sample: position bits (state planes are unpacked at compaction) and pi
+            sb = d.g_self[g];
+            ob = d.g_opp[g];
+            const size_t hidx = (size_t)(gid & d.hist_mask);
+            {
+                const size_t h = hidx * kMaxPly + ply;
+                float* hp = d.hist_pi + h * 65;
+                hp[lane] = pi;
+                if (lane == 0) {
+                    hp[64] = pi64;
+                    d.hist_bits[h * 3 + 0] = sb;
+                    d.hist_bits[h * 3 + 1] = ob;
+                    d.hist_bits[h * 3 + 2] = root.legal;
                 }
             }
-            new_id = __shfl(new_id, 0);
-            if (new_id >= 0) {
-                gid = new_id;
-                nply = 0;
-                sb = kStartSelf;
-                ob = kStartOpp;
+            apply_known(sb, ob, action);  // game.board.make_move(action)
+            nply = ply + 1;
+            over = is_terminal(sb, ob) || nply >= kMaxPly;
+            if (over) {
+                int new_id = -1;
+                if (lane == 0) {
+                    d.game_winner[hidx] = winner(sb, ob);  // relative to the side to move at the end (L16)
+                    d.game_len[hidx] = nply;
+                    d.done_list[atomicAdd(&d.status[ST_DONE], 1) & d.hist_mask] = gid;
+                    if (refill) {
+                        const int nid = atomicAdd(&d.status[ST_NEXT], 1);
+                        if (nid < d.game_limit) {
+                            if (d.game_len[nid & d.hist_mask] == -1) new_id = nid;
+                            else atomicOr(&d.status[ST_FLAGS], FLAG_HIST_OVERFLOW);  // ring entry not harvested yet
+                        }
+                    }
+                }
+                new_id = __shfl(new_id, 0);
+                if (new_id >= 0) {
+                    gid = new_id;
+                    nply = 0;
+                    sb = kStartSelf;
+                    ob = kStartOpp;
+                    next_root = true;
+                    if (lane == 0) d.game_len[gid & d.hist_mask] = 0;
+                }
+            } else {
                 next_root = true;
             }
-        } else {
-            next_root = true;
+        } else if (in_range && d.g_join[g] == d.round && g < d.game_limit) {  // first game of this slot: id = slot
+            gid = g;
+            nply = 0;
+            sb = kStartSelf;
+            ob = kStartOpp;
+            next_root = joined = true;
+            if (lane == 0) {
+                d.game_len[gid & d.hist_mask] = 0;
+                d.g_active[g] = 1;
+                atomicAdd(&d.status[ST_ACTIVE], 1);
+            }
         }
-    }
-    const int cached = next_root ? cache_lookup(d, sb, ob) : -1;
-    int slot = block_alloc_eval(d, bt, next_root && cached < 0, 0, 0, live ? 1 : 0, over ? 1 : 0, cached >= 0 ? 1 : 0);
-    if (!live) return;
-    if (cached >= 0) slot = -(cached + 2);
-    if (next_root) {
-        if (lane == 0) { d.g_id[g] = gid; d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
-        begin_root(d, g, sb, ob, legal_moves(sb, ob), slot, lane);
-    } else if (lane == 0) {
-        d.g_active[g] = 0;
-        d.g_id[g] = -1;
-        d.pend[g] = PEND_NONE;
-        atomicSub(d.n_active, 1);
+        const bool cached = next_root ? cache_fetch(d, g, sb, ob, lane) : false;
+        int slot = block_alloc_eval(d, bt, next_root && !cached, 0, 0, live ? 1 : 0, over ? 1 : 0, cached ? 1 : 0);
+        if (!live && !joined) return;
+        if (cached) slot = kCachedSlot;
+        if (next_root) {
+            if (lane == 0) { d.g_id[g] = gid; d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
+            begin_root(d, g, sb, ob, legal_moves(sb, ob), slot, lane);
+        } else if (lane == 0) {
+            d.g_active[g] = 0;
+            d.g_id[g] = -1;
+            d.pend[g] = PEND_NONE;
+            atomicSub(&d.status[ST_ACTIVE], 1);
+        }
     }
 }
 
@@ -541,14 +582,16 @@ __global__ __launch_bounds__(256) void k_results(Dev d, int n, int temp_zero, fl
 }
 
 // ---- compaction of the replay tuples, game-major then ply (parallel_self_play.py:400-405) --------
-__global__ void k_scan_lengths(const int32_t* __restrict__ len, int64_t* __restrict__ off, int n, int64_t* total) {
+// `list` = game ids to harvest, in output order (nullptr: ids 0..n-1); history entry of id = id & mask.
+__global__ void k_scan_lengths(const int32_t* __restrict__ len, const int32_t* __restrict__ list, int mask,
+                               int64_t* __restrict__ off, int32_t* __restrict__ len_out, int n, int64_t* total) {
     // single block exclusive scan (n <= a few 100k): each thread scans a contiguous chunk
     __shared__ int64_t part[1024];
     const int t = threadIdx.x, T = blockDim.x;
     const int per = (n + T - 1) / T;
     const int lo = t * per, hi = min(lo + per, n);
     int64_t s = 0;
-    for (int i = lo; i < hi; ++i) s += len[i];
+    for (int i = lo; i < hi; ++i) s += max(0, len[(list ? list[i] : i) & mask]);
     part[t] = s;
     __syncthreads();
     if (t == 0) {
@@ -558,20 +601,27 @@ __global__ void k_scan_lengths(const int32_t* __restrict__ len, int64_t* __restr
     }
     __syncthreads();
     int64_t acc = part[t];
-    for (int i = lo; i < hi; ++i) { off[i] = acc; acc += len[i]; }
+    for (int i = lo; i < hi; ++i) {
+        const int l = max(0, len[(list ? list[i] : i) & mask]);
+        off[i] = acc;
+        len_out[i] = l;
+        acc += l;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ hist_bits, const float* __restrict__ hist_pi,
-                                                 const int32_t* __restrict__ len, const int32_t* __restrict__ win,
+                                                 const int32_t* __restrict__ len_out, const int32_t* __restrict__ win,
+                                                 const int32_t* __restrict__ list, int mask,
                                                  const int64_t* __restrict__ off, int num_games,
                                                  float* __restrict__ states, float* __restrict__ pis, float* __restrict__ zs) {
     // one wave per (game, ply) sample; 768 B + 260 B + 4 B written per sample, coalesced rows
     const int lane = threadIdx.x & 63;
     const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int gid = (int)(w / kMaxPly), ply = (int)(w % kMaxPly);
-    if (gid >= num_games || ply >= len[gid]) return;
-    const size_t h = (size_t)gid * kMaxPly + ply;
-    const int64_t o = off[gid] + ply;
+    const int gi = (int)(w / kMaxPly), ply = (int)(w % kMaxPly);
+    if (gi >= num_games || ply >= len_out[gi]) return;
+    const size_t hidx = (size_t)((list ? list[gi] : gi) & mask);
+    const size_t h = hidx * kMaxPly + ply;
+    const int64_t o = off[gi] + ply;
     const uint64_t sb = hist_bits[h * 3], ob = hist_bits[h * 3 + 1], lg = hist_bits[h * 3 + 2];
     float* st = states + o * 192;
     st[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;        // get_tensor_input planes (bitboard.pyx:309-323)
@@ -581,8 +631,20 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ hi
     if (lane == 0) {
         pis[o * 65 + 64] = hist_pi[h * 65 + 64];
         const int player = (ply & 1) ? -1 : 1;           // parallel_self_play.py:385
-        zs[o] = (float)(win[gid] * player);              // parallel_self_play.py:404
+        zs[o] = (float)(win[hidx] * player);              // parallel_self_play.py:404
     }
+}
+
+// policy_probs = torch.exp(policy_logits) (mcts.py:189, parallel_self_play.py:72-76) with the engine's own expf
+__global__ void k_policy_exp(const float* __restrict__ logp, float* __restrict__ probs, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        probs[i] = expf(logp[i]);
+}
+
+// harvested history entries become free again (streaming mode)
+__global__ void k_release(int32_t* __restrict__ game_len, const int32_t* __restrict__ list, int mask, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) game_len[list[i] & mask] = -1;
 }
 
 }  // namespace oth
@@ -597,17 +659,27 @@ struct oth_engine {
     oth_net* net = nullptr;
     Dev d{};
     std::vector<void*> allocs;
-    // per-run buffers
-    int32_t hist_games = 0;
+    int32_t* n_eval2 = nullptr;   // the two evaluation-batch cursors
+    int ev_par = 0;               // cursor the NEXT tree launch fills
+    // history ring + per-harvest buffers
+    int32_t hist_cap = 0;
+    void* hist_allocs[8] = {nullptr};
+    int64_t* d_off = nullptr;
+    int32_t *d_len_out = nullptr, *d_list = nullptr;
     float *out_states = nullptr, *out_pis = nullptr, *out_zs = nullptr;
     int64_t out_cap = 0, n_samples = 0;
-    int64_t* d_off = nullptr;
     int64_t* d_total = nullptr;
     int device = 0;   // HIP device of every allocation of this engine
     int32_t n_roots = 0;
-    int32_t run_games = 0;
-    bool lockstep = false;
+    int32_t run_games = 0;        // games in the last harvest
+    std::vector<int32_t> run_ids; // their ids, in output order
+    bool lockstep = false, streaming = false;
+    int32_t round = 0;            // ply rounds launched since the run / stream began
+    int32_t harvested = 0;        // entries of done_list already harvested
     int64_t counters[8] = {0};
+    // lagged status polling: the status words of round r are copied to pinned memory and checked while round r+1 runs
+    int32_t* h_status = nullptr;  // pinned [2][4]
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -616,7 +688,6 @@ struct oth_engine {
     std::vector<double> net_spans;  // (start, end) ms of every network launch of the last run, on the device's reference-event axis
     double net_ms = 0, tree_ms = 0;
     int64_t net_launches = 0, tree_launches = 0;
-    float* h_stage = nullptr;  // pinned staging for expand inputs given as host pointers
     // result scratch (allocated once): pi/prior f32 [G,65], visits i32 [G,65], value sums f64 [G,65], actions i32 [G]
     float *r_pi = nullptr, *r_prior = nullptr;
     int32_t *r_visits = nullptr, *r_act = nullptr;
@@ -697,57 +768,69 @@ static void spans_reset(oth_engine* e) {
     e->ev_used = 0;
 }
 
+// ---- launches -------------------------------------------------------------------------------------
+// cursor filled by the most recent tree / begin launch (what the network launch that follows must read)
+static inline int32_t* filled_cursor(oth_engine* e) { return e->n_eval2 + (e->ev_par ^ 1); }
+
 static int launch_net(oth_engine* e, hipStream_t s) {
     OTH_CHECK(e->net, "engine has no network: call oth_engine_set_net (or drive an external evaluator "
                       "through oth_search_leaves/oth_search_expand)");
     int r = span_begin(e, s, 0);
     if (r) return r;
-    r = oth_net_forward_bits(e->net, e->d.ev_self, e->d.ev_opp, e->d.ev_legal, e->d.n_slots, e->d.n_eval, e->d.logp,
+    r = oth_net_forward_bits(e->net, e->d.ev_self, e->d.ev_opp, e->d.ev_legal, e->d.n_slots, filled_cursor(e), e->d.logp,
                              e->d.val, s);
     if (r) return r;
     e->counters[4]++;
-    return span_end(e, s);
-}
-static int launch_expand(oth_engine* e, const float* pol, const float* val, int is_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_expand, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, pol, val, is_log);
-    OTH_HIP(hipGetLastError());
-    if (e->d.cmask) {  // insert the fresh network results; a separate launch so that no entry is read while rewritten
+    if ((r = span_end(e, s))) return r;
+    if (e->d.cmask) {  // insert the fresh results before the next tree launch looks the cache up
         e->d.cepoch += 1;
-        hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, pol, val);
+        hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.logp, e->d.val);
         OTH_HIP(hipGetLastError());
     }
     return OTH_OK;
+}
+// bind the cursor pair for the next tree-side launch and flip it
+static inline void bind_cursor(oth_engine* e) {
+    e->d.n_eval = e->n_eval2 + e->ev_par;
+    e->d.n_eval_next = e->n_eval2 + (e->ev_par ^ 1);
+    e->ev_par ^= 1;
+}
+static int launch_tree(oth_engine* e, int mode, int is_log, const int32_t* forced, int refill, hipStream_t s) {
+    int r = span_begin(e, s, 1);
+    if (r) return r;
+    bind_cursor(e);
+    const dim3 grid(blocks_for(e->d.n_slots)), block(256);
+    const size_t lds = sizeof(uint32_t) * 4 * e->d.cap_path;
+    if (mode == TREE_SELECT)
+        hipLaunchKernelGGL(k_tree<TREE_SELECT>, grid, block, lds, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+    else if (mode == TREE_PLY)
+        hipLaunchKernelGGL(k_tree<TREE_PLY>, grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+    else
+        hipLaunchKernelGGL(k_tree<TREE_NONE>, grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+    OTH_HIP(hipGetLastError());
+    return span_end(e, s);
 }
 static int cache_clear(oth_engine* e, hipStream_t s) {
     if (!e->d.cmask) return OTH_OK;
     const size_t C = (size_t)e->d.cmask + 1;
     OTH_HIP(hipMemsetAsync(e->d.ck, 0xFF, C * 2 * sizeof(uint64_t), s));
     OTH_HIP(hipMemsetAsync(e->d.clk, 0, C * sizeof(int32_t), s));
-    OTH_HIP(hipMemsetAsync(e->d.ins, 0, (size_t)e->d.n_slots * sizeof(int32_t), s));
     e->d.cepoch = 0;
     return OTH_OK;
 }
-static int launch_select(oth_engine* e, hipStream_t s) {
-    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_select, dim3(blocks_for(e->d.n_slots)), dim3(256), sizeof(uint32_t) * 4 * e->d.cap_path, s, e->d);
-    OTH_HIP(hipGetLastError());
+static int reset_cursors(oth_engine* e, hipStream_t s) {
+    OTH_HIP(hipMemsetAsync(e->n_eval2, 0, 2 * sizeof(int32_t), s));
+    e->ev_par = 0;
     return OTH_OK;
 }
-// roots already queued: evaluate + expand them, then num_simulations x (select, evaluate, expand)
+// roots already queued: evaluate them, then num_simulations x (expand + select, evaluate); the last expansion is
+// done by the caller's closing tree launch (TREE_NONE for a stand-alone search, TREE_PLY in self-play)
 static int run_search(oth_engine* e, hipStream_t s) {
     int r;
     if ((r = launch_net(e, s))) return r;
-    if ((r = span_begin(e, s, 1))) return r;
-    if ((r = launch_expand(e, e->d.logp, e->d.val, 1, s))) return r;
-    if ((r = span_end(e, s))) return r;
     for (int i = 0; i < e->cfg.num_simulations; ++i) {
-        if ((r = span_begin(e, s, 1))) return r;
-        if ((r = launch_select(e, s))) return r;
-        if ((r = span_end(e, s))) return r;
+        if ((r = launch_tree(e, TREE_SELECT, 1, nullptr, 0, s))) return r;
         if ((r = launch_net(e, s))) return r;
-        if ((r = span_begin(e, s, 1))) return r;
-        if ((r = launch_expand(e, e->d.logp, e->d.val, 1, s))) return r;
-        if ((r = span_end(e, s))) return r;
     }
     return OTH_OK;
 }
@@ -767,27 +850,63 @@ static int read_counters(oth_engine* e, hipStream_t s) {
     return OTH_OK;
 }
 
-static int ensure_history(oth_engine* e, int num_games) {
-    if (num_games <= e->hist_games) return OTH_OK;
-    // (re)allocate per-run history; old buffers stay in allocs until destroy (runs rarely grow)
-    int r;
-    if ((r = dev_alloc(e, &e->d.hist_bits, (size_t)num_games * kMaxPly * 3))) return r;
-    if ((r = dev_alloc(e, &e->d.hist_pi, (size_t)num_games * kMaxPly * 65))) return r;
-    if ((r = dev_alloc(e, &e->d.game_len, (size_t)num_games))) return r;
-    if ((r = dev_alloc(e, &e->d.game_winner, (size_t)num_games))) return r;
-    if ((r = dev_alloc(e, &e->d_off, (size_t)num_games))) return r;
-    e->hist_games = num_games;
+// history ring of `cap` games (power of two).  A larger ring replaces the old one; the old buffers are freed.
+static int ensure_history(oth_engine* e, int min_games) {
+    int cap = 64;
+    while (cap < min_games) cap <<= 1;
+    if (cap <= e->hist_cap) return OTH_OK;
+    for (void*& p : e->hist_allocs) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    e->hist_cap = 0;
+    auto grab = [&](int i, size_t bytes) -> int {
+        OTH_HIP(hipMalloc(&e->hist_allocs[i], bytes));
+        return OTH_OK;
+    };
+    int r = 0;
+    r |= grab(0, sizeof(uint64_t) * (size_t)cap * kMaxPly * 3);
+    r |= grab(1, sizeof(float) * (size_t)cap * kMaxPly * 65);
+    r |= grab(2, sizeof(int32_t) * (size_t)cap);
+    r |= grab(3, sizeof(int32_t) * (size_t)cap);
+    r |= grab(4, sizeof(int32_t) * (size_t)cap);
+    r |= grab(5, sizeof(int64_t) * (size_t)cap);
+    r |= grab(6, sizeof(int32_t) * (size_t)cap);
+    r |= grab(7, sizeof(int32_t) * (size_t)cap);
+    if (r) return OTH_E_HIP;
+    e->d.hist_bits = (uint64_t*)e->hist_allocs[0];
+    e->d.hist_pi = (float*)e->hist_allocs[1];
+    e->d.game_len = (int32_t*)e->hist_allocs[2];
+    e->d.game_winner = (int32_t*)e->hist_allocs[3];
+    e->d.done_list = (int32_t*)e->hist_allocs[4];
+    e->d_off = (int64_t*)e->hist_allocs[5];
+    e->d_len_out = (int32_t*)e->hist_allocs[6];
+    e->d_list = (int32_t*)e->hist_allocs[7];
+    e->hist_cap = cap;
+    e->d.hist_mask = cap - 1;
     return OTH_OK;
 }
 
-static int finish_run(oth_engine* e, int num_games, int64_t* n_samples, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, s, e->d.game_len, e->d_off, num_games, e->d_total);
-    OTH_HIP(hipGetLastError());
+// Compact the replay tuples of `n` games into the output arrays.  ids == nullptr: games 0..n-1 (a finished batch
+// or lock-step run); else the given ids (ascending), whose ring entries are released afterwards.
+static int harvest(oth_engine* e, int n, const int32_t* ids, int64_t* n_samples, hipStream_t s) {
     int64_t total = 0;
-    OTH_HIP(hipMemcpyAsync(&total, e->d_total, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    OTH_HIP(hipStreamSynchronize(s));
+    const int32_t* dlist = nullptr;
+    if (n > 0) {
+        if (ids) {
+            OTH_HIP(hipMemcpyAsync(e->d_list, ids, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+            dlist = e->d_list;
+        }
+        hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, s, e->d.game_len, dlist, e->d.hist_mask, e->d_off,
+                           e->d_len_out, n, e->d_total);
+        OTH_HIP(hipGetLastError());
+        OTH_HIP(hipMemcpyAsync(&total, e->d_total, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        OTH_HIP(hipStreamSynchronize(s));
+    }
     if (total > e->out_cap) {
         if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
+        e->out_states = e->out_pis = e->out_zs = nullptr;
+        e->out_cap = 0;
         const int64_t cap = total + total / 8 + 64;
         OTH_HIP(hipMalloc(&e->out_states, (size_t)cap * 192 * sizeof(float)));
         OTH_HIP(hipMalloc(&e->out_pis, (size_t)cap * 65 * sizeof(float)));
@@ -795,31 +914,76 @@ static int finish_run(oth_engine* e, int num_games, int64_t* n_samples, hipStrea
         e->out_cap = cap;
     }
     if (total > 0) {
-        const int64_t waves = (int64_t)num_games * kMaxPly;
+        const int64_t waves = (int64_t)n * kMaxPly;
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, e->d.hist_bits, e->d.hist_pi,
-                           e->d.game_len, e->d.game_winner, e->d_off, num_games, e->out_states, e->out_pis, e->out_zs);
+                           e->d_len_out, e->d.game_winner, dlist, e->d.hist_mask, e->d_off, n, e->out_states,
+                           e->out_pis, e->out_zs);
         OTH_HIP(hipGetLastError());
     }
-    int rc = read_counters(e, s);
+    if (ids && n > 0) {
+        hipLaunchKernelGGL(k_release, dim3((n + 255) / 256), dim3(256), 0, s, e->d.game_len, dlist, e->d.hist_mask, n);
+        OTH_HIP(hipGetLastError());
+    }
+    int rc = read_counters(e, s);  // synchronises the stream
     if (rc) return rc;
     e->n_samples = total;
-    e->run_games = num_games;
+    e->run_games = n;
+    if (ids) e->run_ids.assign(ids, ids + n);
+    else { e->run_ids.resize((size_t)n); for (int i = 0; i < n; ++i) e->run_ids[(size_t)i] = i; }
     if (n_samples) *n_samples = total;
     return spans_collect(e);
 }
 
-static int reset_run(oth_engine* e, int num_games, uint64_t seed, hipStream_t s) {
-    int r = ensure_history(e, num_games);
+// common start of a batch run / lock-step run / stream: history ring, counters, status words, slots
+static int reset_run(oth_engine* e, int hist_games, int game_limit, int n_start, int stagger, uint64_t seed, hipStream_t s) {
+    int r = ensure_history(e, hist_games);
     if (r) return r;
-    OTH_HIP(hipMemsetAsync(e->d.game_len, 0, sizeof(int32_t) * num_games, s));
+    OTH_HIP(hipMemsetAsync(e->d.game_len, 0xFF, sizeof(int32_t) * (size_t)e->hist_cap, s));  // -1: free
     OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
-    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
-    OTH_HIP(hipMemsetAsync(e->d.n_active, 0, sizeof(int32_t), s));
-    e->d.num_games = num_games;
+    const int32_t st[4] = {0, 0, 0, n_start};
+    OTH_HIP(hipMemcpyAsync(e->d.status, st, sizeof(st), hipMemcpyHostToDevice, s));
+    OTH_HIP(hipStreamSynchronize(s));  // `st` lives on this stack frame
+    if ((r = reset_cursors(e, s))) return r;
+    e->d.game_limit = game_limit;
     e->d.seed = seed;
+    e->d.round = 0;
+    e->round = 0;
+    e->harvested = 0;
     memset(e->counters, 0, sizeof(e->counters));
     spans_reset(e);
-    return cache_clear(e, s);  // the trainer may have changed the weights since the last run
+    if ((r = cache_clear(e, s))) return r;  // the trainer may have changed the weights since the last run
+    hipLaunchKernelGGL(k_slots_init, dim3((e->d.n_slots + 255) / 256), dim3(256), 0, s, e->d, n_start, stagger);
+    OTH_HIP(hipGetLastError());
+    return launch_tree(e, TREE_PLY, 1, nullptr, 0, s);  // round 0: the slots whose join round is 0 start their games
+}
+
+// one ply round of every playing slot: search, then the ply step
+static int run_round(oth_engine* e, const int32_t* forced, int refill, hipStream_t s) {
+    int r = run_search(e, s);
+    if (r) return r;
+    e->round += 1;
+    e->d.round = e->round;
+    return launch_tree(e, TREE_PLY, 1, forced, refill, s);
+}
+
+// copy the status words of the round just enqueued to pinned memory (slot = round parity) and mark it with an event
+static int poll_post(oth_engine* e, hipStream_t s) {
+    const int k = e->round & 1;
+    OTH_HIP(hipMemcpyAsync(e->h_status + 4 * k, e->d.status, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipEventRecord(e->poll_ev[k], s));
+    return OTH_OK;
+}
+// wait for the status words of round `round` (posted with poll_post) and return them
+static int poll_wait(oth_engine* e, int round, const int32_t** st) {
+    const int k = round & 1;
+    OTH_HIP(hipEventSynchronize(e->poll_ev[k]));
+    *st = e->h_status + 4 * k;
+    if ((*st)[ST_FLAGS] & FLAG_HIST_OVERFLOW) {
+        set_error("self-play history ring overflow: a game was still unharvested when its ring entry came up again "
+                  "(raise hist_games / harvest more often)");
+        return OTH_E_STATE;
+    }
+    return OTH_OK;
 }
 
 extern "C" {
@@ -850,6 +1014,7 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     int r = 0;
     r |= dev_alloc(e, &d.g_self, G); r |= dev_alloc(e, &d.g_opp, G);
     r |= dev_alloc(e, &d.g_ply, G); r |= dev_alloc(e, &d.g_id, G); r |= dev_alloc(e, &d.g_active, G);
+    r |= dev_alloc(e, &d.g_join, G);
     r |= dev_alloc(e, &d.nodes, (size_t)G * d.cap_nodes);
     r |= dev_alloc(e, &d.edges, (size_t)G * d.cap_edges);
     r |= dev_alloc(e, &d.n_nodes, G); r |= dev_alloc(e, &d.n_edges, G);
@@ -859,12 +1024,11 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     // the network kernel reads whole tiles of positions: pad the batch arrays
     r |= dev_alloc(e, &d.ev_self, (size_t)G + 64); r |= dev_alloc(e, &d.ev_opp, (size_t)G + 64);
     r |= dev_alloc(e, &d.ev_legal, (size_t)G + 64);
-    r |= dev_alloc(e, &d.n_eval, 4);
+    r |= dev_alloc(e, &e->n_eval2, 4);
     r |= dev_alloc(e, &d.logp, ((size_t)G + 64) * 65); r |= dev_alloc(e, &d.val, (size_t)G + 64);
-    r |= dev_alloc(e, &d.next_game, 4); r |= dev_alloc(e, &d.n_active, 4);
+    r |= dev_alloc(e, &d.status, 4);
     r |= dev_alloc(e, &d.counters, (size_t)blocks_for(G) * 8);
     r |= dev_alloc(e, &e->d_total, 2);
-    r |= dev_alloc(e, &d.ins, G);
     r |= dev_alloc(e, &e->r_pi, (size_t)G * 65); r |= dev_alloc(e, &e->r_prior, (size_t)G * 65);
     r |= dev_alloc(e, &e->r_visits, (size_t)G * 65); r |= dev_alloc(e, &e->r_wsum, (size_t)G * 65);
     r |= dev_alloc(e, &e->r_act, G);
@@ -874,6 +1038,7 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         r |= dev_alloc(e, &d.ck, C * 2);
         r |= dev_alloc(e, &d.cv, C * 66);
         r |= dev_alloc(e, &d.clk, C);
+        r |= dev_alloc(e, &d.cres, (size_t)G * 66);
         if (!r) {
             d.cmask = (uint32_t)(C - 1);
             if (hipMemset(d.ck, 0xFF, C * 2 * sizeof(uint64_t)) != hipSuccess) r = 1;
@@ -881,7 +1046,17 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
     }
     double* st = nullptr;
     r |= dev_alloc(e, &st, (size_t)S + 4);
-    if (r) { oth_engine_destroy(e); return nullptr; }
+    if (!r && hipHostMalloc((void**)&e->h_status, sizeof(int32_t) * 8) != hipSuccess) r = 1;
+    if (!r && (hipEventCreateWithFlags(&e->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&e->poll_ev[1], hipEventDisableTiming) != hipSuccess)) r = 1;
+    if (r) {
+        (void)hipGetLastError();
+        set_error("oth_engine_create: device allocation failed");
+        oth_engine_destroy(e);
+        return nullptr;
+    }
+    e->d.n_eval = e->n_eval2;
+    e->d.n_eval_next = e->n_eval2 + 1;
     std::vector<double> tab(S + 4);
     for (int i = 0; i < S + 4; ++i) tab[i] = sqrt((double)i);  // correctly rounded, == np.sqrt(int)
     if (hipMemcpy(st, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -890,7 +1065,6 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         return nullptr;
     }
     d.sqrt_tab = st;
-    if (hipHostMalloc((void**)&e->h_stage, sizeof(float) * (size_t)G * 66) != hipSuccess) e->h_stage = nullptr;
     return e;
 }
 
@@ -898,9 +1072,11 @@ void oth_engine_destroy(oth_engine* e) {
     if (!e) return;
     (void)bind_device(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
+    for (void* p : e->hist_allocs) if (p) (void)hipFree(p);
     if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    for (auto ev : e->poll_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->h_status) (void)hipHostFree(e->h_status);
     delete e;
 }
 
@@ -916,17 +1092,17 @@ int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int3
     OTH_CHECK(e && sb && ob && n >= 1 && n <= e->d.n_slots, "oth_search_begin: need 1 <= n <= max_games roots");
     OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
+    e->streaming = e->lockstep = false;
     // the roots are uploaded straight into the game-position arrays; k_search_begin reads them there
     OTH_HIP(hipMemcpyAsync(e->d.g_self, sb, sizeof(uint64_t) * n, hipMemcpyDefault, s));
     OTH_HIP(hipMemcpyAsync(e->d.g_opp, ob, sizeof(uint64_t) * n, hipMemcpyDefault, s));
-    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
     OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
     memset(e->counters, 0, sizeof(e->counters));
     spans_reset(e);
-    {
-        int rc = cache_clear(e, s);
-        if (rc) return rc;
-    }
+    int rc = reset_cursors(e, s);
+    if (rc) return rc;
+    if ((rc = cache_clear(e, s))) return rc;
+    bind_cursor(e);
     hipLaunchKernelGGL(k_search_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.g_self, e->d.g_opp, n);
     OTH_HIP(hipGetLastError());
     e->n_roots = n;
@@ -937,7 +1113,7 @@ int oth_search_select(oth_engine* e, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->n_roots > 0, "oth_search_select: call oth_search_begin first");
     OTH_BIND(e->device);
-    return launch_select(e, as_stream(stream));
+    return launch_tree(e, TREE_SELECT, 0, nullptr, 0, as_stream(stream));  // nothing pending: descent only
 }
 
 int oth_search_leaves(oth_engine* e, int32_t* count, uint64_t* sb, uint64_t* ob, uint64_t* lg, void* stream) {
@@ -946,7 +1122,7 @@ int oth_search_leaves(oth_engine* e, int32_t* count, uint64_t* sb, uint64_t* ob,
     OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int32_t n = 0;
-    OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipMemcpyAsync(&n, filled_cursor(e), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OTH_HIP(hipStreamSynchronize(s));
     *count = n;
     if (n > 0) {
@@ -964,20 +1140,28 @@ int oth_search_expand(oth_engine* e, const float* policy, const float* value, in
     OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
     int32_t n = 0;
-    OTH_HIP(hipMemcpyAsync(&n, e->d.n_eval, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipMemcpyAsync(&n, filled_cursor(e), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OTH_HIP(hipStreamSynchronize(s));
     if (n > 0) {  // caller memory may be host or device: stage into the engine's own arrays
         OTH_HIP(hipMemcpyAsync(e->d.logp, policy, sizeof(float) * 65 * n, hipMemcpyDefault, s));
         OTH_HIP(hipMemcpyAsync(e->d.val, value, sizeof(float) * n, hipMemcpyDefault, s));
+        if (e->d.cmask) {
+            e->d.cepoch += 1;
+            hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.logp, e->d.val);
+            OTH_HIP(hipGetLastError());
+        }
     }
-    return launch_expand(e, e->d.logp, e->d.val, is_log ? 1 : 0, s);
+    return launch_tree(e, TREE_NONE, is_log ? 1 : 0, nullptr, 0, s);
 }
 
 int oth_search_run(oth_engine* e, void* stream) {
     OTH_NEED_DEVICE();
     OTH_CHECK(e && e->n_roots > 0, "oth_search_run: call oth_search_begin first");
     OTH_BIND(e->device);
-    return run_search(e, as_stream(stream));
+    hipStream_t s = as_stream(stream);
+    int r = run_search(e, s);
+    if (r) return r;
+    return launch_tree(e, TREE_NONE, 1, nullptr, 0, s);
 }
 
 int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* visits, double* wsum, float* prior,
@@ -1012,32 +1196,37 @@ int oth_selfplay_run(oth_engine* e, int32_t num_games, uint64_t seed, int32_t ad
     OTH_BIND(e->device);
     OTH_CHECK(e->net, "oth_selfplay_run: no network set");
     hipStream_t s = as_stream(stream);
-    int r = reset_run(e, num_games, seed, s);
-    if (r) return r;
     const int G = e->d.n_slots;
     const int n_start = num_games < G ? num_games : G;
-    OTH_HIP(hipMemcpyAsync(e->d.next_game, &n_start, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_games_begin, dim3(blocks_for(G)), dim3(256), 0, s, e->d, n_start);
-    OTH_HIP(hipGetLastError());
-    e->lockstep = false;
+    int r = reset_run(e, num_games, num_games, n_start, 0, seed, s);
+    if (r) return r;
+    e->lockstep = e->streaming = false;
     e->n_roots = 0;
-    for (int64_t step = 0;; ++step) {
-        if ((r = run_search(e, s))) return r;
-        if ((r = span_begin(e, s, 1))) return r;
-        OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
-        hipLaunchKernelGGL(k_ply, dim3(blocks_for(G)), dim3(256), 0, s, e->d, (const int32_t*)nullptr, 1);
-        OTH_HIP(hipGetLastError());
-        if ((r = span_end(e, s))) return r;
-        int32_t active = 0;
-        OTH_HIP(hipMemcpyAsync(&active, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        OTH_HIP(hipStreamSynchronize(s));
-        if (active <= 0) break;
-        if (step > (int64_t)kMaxPly * ((num_games + G - 1) / G + 1)) {
+    const int64_t max_rounds = (int64_t)kMaxPly * ((num_games + G - 1) / G + 1) + 2;
+    // The host stays one round ahead: round r is enqueued, then the status words of round r-1 are checked, so the
+    // device never waits for the host.  The round enqueued after the last game ended finds no playing slot.
+    for (;;) {
+        if ((r = run_round(e, nullptr, 1, s))) return r;
+        if ((r = poll_post(e, s))) return r;
+        if (e->round >= 2) {
+            const int32_t* st = nullptr;
+            if ((r = poll_wait(e, e->round - 1, &st))) return r;
+            if (st[ST_ACTIVE] <= 0) break;
+        }
+        if (e->round > max_rounds) {
             set_error("oth_selfplay_run: games did not finish (internal error)");
             return OTH_E_STATE;
         }
     }
-    return finish_run(e, num_games, n_samples, s);
+    {   // the round enqueued last found nothing to do; wait for it (and for its flags)
+        const int32_t* st = nullptr;
+        if ((r = poll_wait(e, e->round, &st))) return r;
+        if (st[ST_ACTIVE] > 0) {
+            set_error("oth_selfplay_run: slots still playing after the final round (internal error)");
+            return OTH_E_STATE;
+        }
+    }
+    return harvest(e, num_games, nullptr, n_samples, s);
 }
 
 int oth_selfplay_begin(oth_engine* e, int32_t n, void* stream) {
@@ -1045,12 +1234,10 @@ int oth_selfplay_begin(oth_engine* e, int32_t n, void* stream) {
     OTH_CHECK(e && n >= 1 && n <= e->d.n_slots, "oth_selfplay_begin: need 1 <= n <= max_games");
     OTH_BIND(e->device);
     hipStream_t s = as_stream(stream);
-    int r = reset_run(e, n, 0, s);
+    int r = reset_run(e, n, n, n, 0, 0, s);
     if (r) return r;
-    OTH_HIP(hipMemcpyAsync(e->d.next_game, &n, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_games_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, n);
-    OTH_HIP(hipGetLastError());
     e->lockstep = true;
+    e->streaming = false;
     e->n_roots = n;
     return OTH_OK;
 }
@@ -1062,6 +1249,7 @@ int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream)
     hipStream_t s = as_stream(stream);
     int r = run_search(e, s);
     if (r) return r;
+    if ((r = launch_tree(e, TREE_NONE, 1, nullptr, 0, s))) return r;   // last expansion: the root statistics are final
     const int n = e->n_roots;
     if (active) OTH_HIP(hipMemcpyAsync(active, e->d.g_active, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     if (pi) {
@@ -1085,13 +1273,14 @@ int oth_selfplay_apply(oth_engine* e, const int32_t* actions, int32_t* n_unfinis
     int32_t* dact = e->r_act;
     OTH_HIP(hipMemsetAsync(dact, 0, sizeof(int32_t) * e->d.n_slots, s));
     OTH_HIP(hipMemcpyAsync(dact, actions, sizeof(int32_t) * e->n_roots, hipMemcpyDefault, s));
-    OTH_HIP(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_ply, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, (const int32_t*)dact, 0);
-    OTH_HIP(hipGetLastError());
-    int32_t act = 0;
-    OTH_HIP(hipMemcpyAsync(&act, e->d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    e->round += 1;
+    e->d.round = e->round;
+    int r = launch_tree(e, TREE_PLY, 1, dact, 0, s);  // nothing pending (oth_selfplay_search expanded everything)
+    if (r) return r;
+    int32_t st[4] = {0, 0, 0, 0};
+    OTH_HIP(hipMemcpyAsync(st, e->d.status, sizeof(st), hipMemcpyDeviceToHost, s));
     OTH_HIP(hipStreamSynchronize(s));
-    if (n_unfinished) *n_unfinished = act;
+    if (n_unfinished) *n_unfinished = st[ST_ACTIVE];
     return OTH_OK;
 }
 
@@ -1102,7 +1291,93 @@ int oth_selfplay_end(oth_engine* e, int64_t* n_samples, void* stream) {
     e->lockstep = false;
     const int n = e->n_roots;
     e->n_roots = 0;
-    return finish_run(e, n, n_samples, as_stream(stream));
+    return harvest(e, n, nullptr, n_samples, as_stream(stream));
+}
+
+// ---- streaming self-play -------------------------------------------------------------------------
+int oth_stream_begin(oth_engine* e, uint64_t seed, int32_t stagger_rounds, int32_t hist_games, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && stagger_rounds >= 0 && hist_games >= 0, "oth_stream_begin: bad arguments");
+    OTH_BIND(e->device);
+    OTH_CHECK(e->net, "oth_stream_begin: no network set");
+    hipStream_t s = as_stream(stream);
+    const int G = e->d.n_slots;
+    const int64_t want = hist_games > 0 ? hist_games : (int64_t)8 * G;
+    OTH_CHECK(want >= 2 * (int64_t)G && want <= (1 << 24), "oth_stream_begin: hist_games must be in [2*max_games, 2^24]");
+    int r = reset_run(e, (int)want, INT_MAX, G, stagger_rounds, seed, s);
+    if (r) return r;
+    e->streaming = true;
+    e->lockstep = false;
+    e->n_roots = 0;
+    return OTH_OK;
+}
+
+int oth_stream_step(oth_engine* e, int32_t min_games, int32_t* n_games, int64_t* n_samples, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->streaming, "oth_stream_step: call oth_stream_begin first");
+    OTH_CHECK(min_games >= 1 && min_games <= e->hist_cap - 2 * e->d.n_slots,
+              "oth_stream_step: min_games must be in [1, hist_games - 2*max_games]");
+    OTH_BIND(e->device);
+    hipStream_t s = as_stream(stream);
+    spans_reset(e);
+    int r;
+    // Rounds are enqueued one ahead of the check (see oth_selfplay_run): the step ends with the round that was
+    // already in flight when the round before it was seen to reach the target -- a deterministic rule.
+    const int first = e->round + 1;
+    for (;;) {
+        if ((r = run_round(e, nullptr, 1, s))) return r;
+        if ((r = poll_post(e, s))) return r;
+        if (e->round > first) {
+            const int32_t* st = nullptr;
+            if ((r = poll_wait(e, e->round - 1, &st))) return r;
+            if (st[ST_DONE] - e->harvested >= min_games) break;
+        }
+        if (e->round - first > 4 * kMaxPly + min_games) {
+            set_error("oth_stream_step: no progress (internal error)");
+            return OTH_E_STATE;
+        }
+    }
+    const int32_t* st = nullptr;
+    if ((r = poll_wait(e, e->round, &st))) return r;
+    const int done = st[ST_DONE];
+    const int n = done - e->harvested;
+    OTH_CHECK(n <= e->hist_cap, "oth_stream_step: more finished games than the history ring holds");
+    std::vector<int32_t> ids((size_t)n);
+    if (n > 0) {
+        const int mask = e->d.hist_mask, b0 = e->harvested & mask;
+        const int first_part = std::min(n, e->hist_cap - b0);
+        OTH_HIP(hipMemcpyAsync(ids.data(), e->d.done_list + b0, sizeof(int32_t) * (size_t)first_part, hipMemcpyDeviceToHost, s));
+        if (n > first_part)
+            OTH_HIP(hipMemcpyAsync(ids.data() + first_part, e->d.done_list, sizeof(int32_t) * (size_t)(n - first_part),
+                                   hipMemcpyDeviceToHost, s));
+        OTH_HIP(hipStreamSynchronize(s));
+        std::sort(ids.begin(), ids.end());
+    }
+    e->harvested = done;
+    if (n_games) *n_games = n;
+    return harvest(e, n, ids.data(), n_samples, s);
+}
+
+int oth_selfplay_game_ids(oth_engine* e, int32_t* ids, int32_t capacity, int32_t* count) {
+    OTH_CHECK(e && count, "oth_selfplay_game_ids: null argument");
+    *count = e->run_games;
+    if (ids) {
+        const int m = e->run_games < capacity ? e->run_games : capacity;
+        for (int i = 0; i < m; ++i) ids[i] = e->run_ids[(size_t)i];
+    }
+    return OTH_OK;
+}
+
+int oth_policy_exp(const float* logp, float* probs, int64_t n, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(n >= 0 && (n == 0 || (logp && probs)), "oth_policy_exp: bad arguments");
+    if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(logp);
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_policy_exp, dim3((unsigned)g), dim3(256), 0, as_stream(stream), logp, probs, n);
+    OTH_HIP(hipGetLastError());
+    return OTH_OK;
 }
 
 int oth_selfplay_fetch(oth_engine* e, float* states, float* pis, float* zs, int32_t* game_len, void* stream) {
@@ -1117,7 +1392,7 @@ int oth_selfplay_fetch(oth_engine* e, float* states, float* pis, float* zs, int3
         if (zs) OTH_HIP(hipMemcpyAsync(zs, e->out_zs, (size_t)n * sizeof(float), hipMemcpyDefault, s));
     }
     if (game_len && e->run_games > 0)
-        OTH_HIP(hipMemcpyAsync(game_len, e->d.game_len, sizeof(int32_t) * e->run_games, hipMemcpyDefault, s));
+        OTH_HIP(hipMemcpyAsync(game_len, e->d_len_out, sizeof(int32_t) * e->run_games, hipMemcpyDefault, s));
     OTH_HIP(hipStreamSynchronize(s));
     return OTH_OK;
 }

@@ -79,6 +79,14 @@ class HipResNetEvaluator:
                   n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
         return logp, v.view(n, 1)
 
+    def policy_probs(self, logp):
+        """exp(log-probs) with the engine's own expf (what the expansion feeds node.py:71-80): CUDA tensor in/out."""
+        import torch
+        logp = logp.contiguous()
+        out = torch.empty_like(logp)
+        _lib.call("oth_policy_exp", logp.data_ptr(), out.data_ptr(), logp.numel(), _lib.current_stream())
+        return out
+
     def __del__(self):
         try:
             if self._h:
@@ -176,6 +184,27 @@ class SearchEngine:
                   1 if add_noise else 0, C.byref(n), _lib.current_stream())
         self._run_games = int(num_games)
         return n.value
+
+    # ---- streaming self-play: the slots stay full across steps ------------------------------
+    def stream_begin(self, seed, stagger_rounds=0, hist_games=0):
+        _lib.call("oth_stream_begin", self._h, C.c_uint64(int(seed) & (2**64 - 1)), int(stagger_rounds),
+                  int(hist_games), _lib.current_stream())
+
+    def stream_step(self, min_games):
+        """Play until >= min_games more games have finished; -> (games, samples) of this step's harvest."""
+        g, n = C.c_int32(0), C.c_int64(0)
+        _lib.call("oth_stream_step", self._h, int(min_games), C.byref(g), C.byref(n), _lib.current_stream())
+        self._run_games = g.value
+        return g.value, n.value
+
+    def game_ids(self):
+        """ids of the games of the last run / step, in output order."""
+        cnt = C.c_int32(0)
+        _lib.call("oth_selfplay_game_ids", self._h, None, 0, C.byref(cnt))
+        ids = np.zeros(cnt.value, dtype=np.int32)
+        if cnt.value:
+            _lib.call("oth_selfplay_game_ids", self._h, _lib.np_ptr(ids, C.c_int32), cnt.value, C.byref(cnt))
+        return ids
 
     def selfplay_begin(self, n):
         self._n = int(n)

@@ -28,7 +28,11 @@ class BatchMCTS:
         self.c_puct = c_puct
         self.dirichlet_alpha = dirichlet_alpha
         self.dirichlet_epsilon = dirichlet_epsilon
+        # evaluator: a HipResNetEvaluator (default: built from `model`), or any object with
+        # host_eval(self u64[m], opp u64[m], legal u64[m]) -> (probs f32[m,65], values f32[m]) -- an external
+        # evaluator driven through oth_search_leaves / oth_search_expand (stub evaluators of the parity tests)
         self.evaluator = evaluator or HipResNetEvaluator(model, precision=precision)
+        self._external = hasattr(self.evaluator, "host_eval")
         self._engines = {}
 
     def _engine(self, n_boards, num_simulations):
@@ -40,7 +44,8 @@ class BatchMCTS:
         if eng is None:
             eng = SearchEngine(cap, num_simulations, c_puct=self.c_puct,
                                dirichlet_alpha=self.dirichlet_alpha,
-                               dirichlet_epsilon=self.dirichlet_epsilon, evaluator=self.evaluator)
+                               dirichlet_epsilon=self.dirichlet_epsilon,
+                               evaluator=None if self._external else self.evaluator)
             self._engines[key] = eng
         return eng
 
@@ -50,14 +55,19 @@ class BatchMCTS:
             return []
         if temperature not in (0, 0.0, 1, 1.0):
             raise ValueError("temperature must be 0 or 1")
-        self.evaluator.refresh()
+        if not self._external:
+            self.evaluator.refresh()
         if add_dirichlet_noise:  # :111-118: one draw per board, in board order
             for b in boards:
                 np.random.dirichlet([self.dirichlet_alpha] * len(b.get_legal_moves()))
         eng = self._engine(n, num_simulations)
-        eng.search_begin([b.self_board for b in boards], [b.opp_board for b in boards])
-        eng.search_run()
-        pi, _, _, _ = eng.search_results(float(temperature))
+        sb, ob = [b.self_board for b in boards], [b.opp_board for b in boards]
+        if self._external:
+            pi, _, _, _ = eng.search_with(sb, ob, self.evaluator.host_eval, float(temperature))
+        else:
+            eng.search_begin(sb, ob)
+            eng.search_run()
+            pi, _, _, _ = eng.search_results(float(temperature))
         return [(pi[i].copy(), 0.0) for i in range(n)]  # root value is always 0.0
 
 

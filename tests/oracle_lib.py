@@ -85,6 +85,14 @@ def lib():
             f.restype = C.c_int64
             f.argtypes = [C.POINTER(SelfplayCfg), C.c_int, EVAL_FN, C.c_void_p, C.POINTER(Rng),
                           C.c_int64, f32p, f32p, f32p, i32p]
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox_uniform.restype = C.c_double
+        L.orc_philox_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_choice_cdf.restype = C.c_int
+        L.orc_choice_cdf.argtypes = [f32p, C.c_double]
+        L.orc_selfplay_philox.restype = C.c_int64
+        L.orc_selfplay_philox.argtypes = [C.POINTER(SelfplayCfg), C.c_int, C.c_uint64, C.c_int, EVAL_FN, C.c_void_p,
+                                          C.c_int64, f32p, f32p, f32p, i32p, i32p]
         L.orc_net_blob_floats.restype = C.c_int64
         L.orc_net_blob_floats.argtypes = [C.c_int, C.c_int]
         L.orc_net_create.restype = C.c_void_p
@@ -95,6 +103,10 @@ def lib():
         L.orc_cpu_baseline.restype = C.c_int64
         L.orc_cpu_baseline.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int,
                                        C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_cpu_baseline_spread.restype = C.c_int64
+        L.orc_cpu_baseline_spread.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int, C.c_int,
+                                              C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -220,6 +232,40 @@ def selfplay(kind, num_episodes, sims, threshold, eval_cb, rng=None, parallel_ga
            _p(st, C.c_float), _p(pi, C.c_float), _p(z, C.c_float), _p(mv, C.c_int32))
     assert n >= 0
     return st[:n], pi[:n], z[:n], mv[:n]
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return tuple(o)
+
+
+def philox_uniform(seed, game_id, ply):
+    return lib().orc_philox_uniform(C.c_uint64(seed), game_id, ply)
+
+
+def choice_cdf(pi, u):
+    pi = np.ascontiguousarray(pi, dtype=np.float32)
+    return lib().orc_choice_cdf(_p(pi, C.c_float), float(u))
+
+
+def selfplay_philox(num_games, seed, sims, threshold, eval_cb, parallel_games=64, c_puct=1.0, late_onehot=False,
+                    eval_ctx=None):
+    """The engine's device-RNG self-play restated on the CPU: -> states, pis, zs, moves, game_len."""
+    cfg = SelfplayCfg(sims, threshold, parallel_games, c_puct, 0.3, 0.25, 0, 0)
+    cap = num_games * 130
+    st = np.zeros((cap, 3, 8, 8), dtype=np.float32)
+    pi = np.zeros((cap, 65), dtype=np.float32)
+    z = np.zeros(cap, dtype=np.float32)
+    mv = np.zeros(cap, dtype=np.int32)
+    gl = np.zeros(num_games, dtype=np.int32)
+    n = lib().orc_selfplay_philox(C.byref(cfg), num_games, C.c_uint64(seed), int(late_onehot), eval_cb, eval_ctx, cap,
+                                  _p(st, C.c_float), _p(pi, C.c_float), _p(z, C.c_float), _p(mv, C.c_int32),
+                                  _p(gl, C.c_int32))
+    assert n >= 0
+    return st[:n], pi[:n], z[:n], mv[:n], gl
 
 
 # ---------------------------------------------------------------------------------- network

@@ -228,3 +228,83 @@ def test_live_reference_rules_if_present():
         st, ps = ol.symmetries(ob, pi)
         for k, (rs, rp) in enumerate(b.get_symmetries(pi)):
             assert np.array_equal(st[k], rs) and np.array_equal(ps[k], rp)
+
+
+# ===================================================================== device-RNG restatement (a12)
+def test_philox4x32_10_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution,
+    Salmon et al. SC'11): counter, key -> output."""
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        assert ol.philox4x32_10(ctr, key) == want
+
+
+def test_philox_uniform_keying():
+    """uniform = ((o0 >> 5) * 2^26 + (o1 >> 6)) / 2^53 of philox(ctr = (game, ply, 0x2545F491, 0x9E3779B9), key = seed)."""
+    for seed, gid, ply in [(0, 0, 0), (42, 7, 3), (2**63 + 12345, 4095, 127), (2**64 - 1, 2**31 - 1, 59)]:
+        o = ol.philox4x32_10((gid, ply, 0x2545F491, 0x9E3779B9), (seed & 0xffffffff, seed >> 32))
+        want = ((o[0] >> 5) * 67108864.0 + (o[1] >> 6)) / 9007199254740992.0
+        u = ol.philox_uniform(seed, gid, ply)
+        assert u == want and 0.0 <= u < 1.0
+
+
+def test_choice_cdf_is_numpy_choice():
+    """orc_choice_cdf(pi, u) == numpy's RandomState.choice(65, p=pi) when numpy's own uniform draw is u."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    for case in range(3000):
+        k = int(rng.integers(1, 20))
+        counts = np.zeros(65, dtype=np.int64)
+        idx = rng.choice(65, size=k, replace=False)
+        counts[idx] = rng.integers(1, 50, size=k)
+        if case % 7 == 0:
+            counts[:] = 0
+            counts[64] = 5          # pass-only distribution
+        pi = (counts.astype(np.float32) / np.float32(counts.sum())).astype(np.float32)
+        seed = int(rng.integers(0, 2**31))
+        u = np.random.RandomState(seed).random_sample()
+        want = int(np.random.RandomState(seed).choice(65, p=pi))
+        assert ol.choice_cdf(pi, u) == want
+    # boundaries: u just below / at a cdf step
+    pi = np.zeros(65, dtype=np.float32)
+    pi[3], pi[10] = 0.25, 0.75
+    assert ol.choice_cdf(pi, 0.0) == 3 and ol.choice_cdf(pi, 0.25) == 10
+    assert ol.choice_cdf(pi, np.nextafter(0.25, 0)) == 3 and ol.choice_cdf(pi, np.nextafter(1.0, 0)) == 10
+
+
+def test_selfplay_philox_matches_parallel_loop_with_same_draws(golden):
+    """orc_selfplay_philox == orc_selfplay_parallel (pinned by g5) when the latter's choice() callback replays the
+    Philox draws: same loop, only the source of the uniform differs."""
+    from stub_eval import stub_probs_values
+    table = golden("g3_search.npz")["stub_exp"]
+    ev = ol.make_eval(lambda s, o: stub_probs_values(s, o, table))
+    seed, games, sims, thr = 99, 6, 6, 8
+    st, pi, z, mv, gl = ol.selfplay_philox(games, seed, sims, thr, ev, parallel_games=6)
+    assert gl.sum() == len(z) and len(gl) == games
+    # replay game by game through the golden-pinned loop with a choice callback that knows (game, ply)
+    off = 0
+    for g in range(games):
+        state = {"ply": 0}
+
+        def _choice(ctx, p, g=g, state=state):
+            arr = np.ctypeslib.as_array(p, shape=(65,)).copy()
+            a = ol.choice_cdf(arr, ol.philox_uniform(seed, g, state["ply"]))
+            return a
+        calls = {"n": 0}
+
+        def _choice_counting(ctx, p):
+            a = _choice(ctx, p)
+            state["ply"] += 1
+            calls["n"] += 1
+            return a
+        r = ol.Rng(ol.DIR_FN(lambda c, a, n, o: None), ol.CHOICE_FN(_choice_counting), None)
+        s1, p1, z1, m1 = ol.selfplay("parallel", 1, sims, thr, ev, rng=r, parallel_games=1, add_noise=False)
+        n = int(gl[g])
+        assert len(z1) == n and calls["n"] == min(n, thr)
+        assert np.array_equal(s1, st[off:off + n]) and np.array_equal(p1, pi[off:off + n])
+        assert np.array_equal(z1, z[off:off + n]) and np.array_equal(m1, mv[off:off + n])
+        off += n
