@@ -78,12 +78,16 @@ int oth_rules_checksum(int64_t n, uint64_t *legal_acc /*HOST*/, uint64_t *flip_a
  * 3. Evaluator: OthelloResNet forward (src/model/net.py:139-205), eval mode
  * =========================================================================================== */
 typedef struct oth_net oth_net;
-#define OTH_PREC_F32 0     /* generic fp32 VALU kernel (any filter count) */
+#define OTH_PREC_F32 0     /* exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32): 16/32/64/128 filters, 8x8 and 6x6 */
 #define OTH_PREC_F16X3 1   /* MFMA, fp16 hi/lo split of both operands, fp32 accumulate (fp32-equivalent) */
 #define OTH_PREC_F16 2     /* MFMA, single fp16 pass (fast; NOT within the 1e-4 parity tolerance in general) */
 
-/* net.py:157-180 __init__(num_blocks, num_filters, board_size).  board_size must be 8. */
+/* net.py:157-180 __init__(num_blocks, num_filters, board_size).  board_size 8 or 6 (configs/debug_6x6.yaml);
+ * num_filters 16, 32, 64 or 128.  A 6x6 network takes positions as bit i = row*6 + col (i < 36) and returns
+ * 37 log-probabilities per position. */
 oth_net *oth_net_create(int num_blocks, int num_filters, int board_size);
+/* board_size^2 + 1: length of a policy row of this network (65 or 37) */
+int oth_net_policy_size(const oth_net *net);
 void oth_net_destroy(oth_net *net);
 /* number of float32 values oth_net_load_state expects */
 int64_t oth_net_state_floats(const oth_net *net);
@@ -93,11 +97,11 @@ int64_t oth_net_state_floats(const oth_net *net);
  * the weights repacked for the kernels.  Call again whenever the trainer has updated the model. */
 int oth_net_load_state(oth_net *net, const float *blob, int64_t n_floats, int precision);
 /* forward(x) for x given as packed bitboards (self, opp, legal planes of get_tensor_input).
- * logp: [n,65] log-probabilities, v: [n].  all DEVICE.  n_valid (DEVICE int32*, may be NULL): when
+ * logp: [n,65] ([n,37] for a 6x6 network) log-probabilities, v: [n].  all DEVICE.  n_valid (DEVICE int32*, may be NULL): when
  * given, only the first *n_valid (<= n) positions are evaluated (device-side batch length). */
 int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *opp_b, const uint64_t *legal,
                          int64_t n, const int32_t *n_valid, float *logp, float *v, void *stream);
-/* forward(x) for x float32 [n,3,8,8] holding 0/1 planes (the reference's input format) DEVICE */
+/* forward(x) for x float32 [n,3,S,S] holding 0/1 planes (the reference's input format) DEVICE */
 int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
 
 /* probs[i] = exp(logp[i]) exactly as the engine's expansion computes it from the network's log-probabilities

@@ -59,6 +59,7 @@ _SIGS = {
     "oth_net_create": (vp, [C.c_int, C.c_int, C.c_int]),
     "oth_net_destroy": (None, [vp]),
     "oth_net_state_floats": (C.c_int64, [vp]),
+    "oth_net_policy_size": (C.c_int, [vp]),
     "oth_net_load_state": (C.c_int, [vp, f32p, C.c_int64, C.c_int]),
     "oth_net_forward_bits": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
     "oth_net_forward_planes": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
@@ -88,7 +89,7 @@ _SIGS = {
     "oth_engine_net_spans": (C.c_int, [vp, f64p, C.c_int64, i64p]),
     "oth_augment_symmetries": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
 }
-_PLAIN_INT = {"oth_device_available", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}
+_PLAIN_INT = {"oth_device_available", "oth_net_policy_size", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}
 
 _lib = None
 

@@ -1,5 +1,5 @@
-// net.h -- evaluator object shared by net.hip (generic fp32 kernel + API) and net_mfma.hip
-// (the F=128 MFMA trunk kernel).
+// net.h -- evaluator object shared by net.hip (API, weight folding), net_f32.hip (exact-fp32 MFMA trunk, every
+// width and board size) and net_mfma.hip (the fp16-split MFMA trunk for 128 filters).
 #pragma once
 #include <vector>
 
@@ -16,13 +16,15 @@ struct FoldedConv {
     std::vector<float> bias;  // [cout]
 };
 
+constexpr int kMaxTrunkLayers = 48;  // 1 + 2*blocks
+
 struct HostNet {
-    int blocks = 0, filters = 0;
+    int blocks = 0, filters = 0, board = 8;
     FoldedConv stem;               // 3 -> F, 3x3            (net.py:168)
     std::vector<FoldedConv> res;   // 2*blocks, F -> F, 3x3  (net.py:171-173)
     FoldedConv pconv, vconv;       // 1x1 heads              (net.py:76, 111)
-    std::vector<float> pfc_w, pfc_b;    // [65][128], [65]   (net.py:81)
-    std::vector<float> vfc1_w, vfc1_b;  // [256][64], [256]  (net.py:116)
+    std::vector<float> pfc_w, pfc_b;    // [cells+1][2*cells], [cells+1]   (net.py:81; 8x8: [65][128])
+    std::vector<float> vfc1_w, vfc1_b;  // [256][cells], [256]             (net.py:116)
     std::vector<float> vfc2_w, vfc2_b;  // [256], [1]        (net.py:117)
 };
 
@@ -41,19 +43,20 @@ struct HeadParams {
 };
 
 struct MfmaWeights;  // net_mfma.hip
+struct F32Weights;   // net_f32.hip
 
 }  // namespace oth
 
 struct oth_net {
     int device = 0;      // HIP device the weights live on (the creating thread's current device)
-    int blocks = 0, filters = 0;
+    int blocks = 0, filters = 0, board = 8;
     int precision = -1;  // OTH_PREC_*; -1 = no weights loaded
     oth::HostNet host;
-    // generic fp32 path
-    float* d_generic = nullptr;  // one allocation: all folded convs + heads
-    std::vector<size_t> conv_w_off, conv_b_off;  // per conv layer (stem, res...), float offsets
+    float* d_heads = nullptr;  // one allocation: the fp32 head parameters (shared by both trunk kernels)
     oth::HeadParams heads{};
-    // MFMA path (filters == 128)
+    // exact-fp32 MFMA path (any filter count, 8x8 and 6x6): net_f32.hip
+    oth::F32Weights* f32 = nullptr;
+    // fp16-split MFMA path (128 filters, 8x8): net_mfma.hip
     oth::MfmaWeights* mfma = nullptr;
 };
 
@@ -62,4 +65,8 @@ int mfma_pack_weights(oth_net* net, int precision);  // net_mfma.hip
 void mfma_free_weights(oth_net* net);
 int mfma_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
                  const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
+int f32_pack_weights(oth_net* net);  // net_f32.hip
+void f32_free_weights(oth_net* net);
+int f32_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
+                const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 }  // namespace oth

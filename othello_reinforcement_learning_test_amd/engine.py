@@ -9,10 +9,10 @@ import numpy as np
 from . import _lib
 
 
-def default_precision(num_filters):
-    """128-filter networks run on the MFMA trunk with the fp32-equivalent fp16x3 split; other
-    widths use the generic fp32 kernel."""
-    return "f16x3" if num_filters == 128 else "f32"
+def default_precision(num_filters, board_size=8):
+    """128-filter networks on 8x8 run on the fp16-split MFMA trunk (fp32-equivalent, the benchmarked kernel); every
+    other width / board size runs the exact-fp32 MFMA trunk."""
+    return "f16x3" if (num_filters == 128 and board_size == 8) else "f32"
 
 
 class HipResNetEvaluator:
@@ -30,7 +30,9 @@ class HipResNetEvaluator:
         self.num_blocks = int(getattr(model, "num_blocks", len(model.res_blocks)))
         self.num_filters = int(getattr(model, "num_filters", model.conv_block.conv.out_channels))
         board_size = int(getattr(model, "board_size", 8))
-        self.precision = precision or default_precision(self.num_filters)
+        self.board_size = board_size
+        self.policy_size = board_size * board_size + 1
+        self.precision = precision or default_precision(self.num_filters, board_size)
         if self.precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self._h = _lib.load().oth_net_create(self.num_blocks, self.num_filters, board_size)
@@ -59,11 +61,13 @@ class HipResNetEvaluator:
         return self._h
 
     def forward_planes(self, x):
-        """x: CUDA float32 (N,3,8,8) of 0/1 planes -> (log-probs (N,65), value (N,1)) CUDA tensors."""
+        """x: CUDA float32 (N,3,S,S) of 0/1 planes -> (log-probs (N,S*S+1), value (N,1)) CUDA tensors."""
         import torch
         x = x.contiguous()
         n = x.shape[0]
-        logp = torch.empty((n, 65), dtype=torch.float32, device=x.device)
+        if tuple(x.shape[1:]) != (3, self.board_size, self.board_size):
+            raise ValueError("expected input of shape (N,3,%d,%d)" % (self.board_size, self.board_size))
+        logp = torch.empty((n, self.policy_size), dtype=torch.float32, device=x.device)
         v = torch.empty((n,), dtype=torch.float32, device=x.device)
         _lib.call("oth_net_forward_planes", self._h, x.data_ptr(), n, logp.data_ptr(), v.data_ptr(),
                   _lib.current_stream())
@@ -73,7 +77,7 @@ class HipResNetEvaluator:
         """Packed-bitboard input (CUDA int64 tensors) -> (log-probs, value)."""
         import torch
         n = self_b.numel()
-        logp = torch.empty((n, 65), dtype=torch.float32, device=self_b.device)
+        logp = torch.empty((n, self.policy_size), dtype=torch.float32, device=self_b.device)
         v = torch.empty((n,), dtype=torch.float32, device=self_b.device)
         _lib.call("oth_net_forward_bits", self._h, self_b.data_ptr(), opp_b.data_ptr(), legal.data_ptr(),
                   n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())

@@ -255,6 +255,73 @@ def test_net_forward_vs_reference_outputs(pkg, golden, seed):
             assert np.allclose(np.exp(logp.cpu().numpy()).sum(1), 1.0, atol=1e-5)  # test_model.py:63-75
 
 
+NETS6 = [(2, 16), (2, 32), (5, 64), (3, 128)]
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+def test_net6_forward_vs_reference_outputs(pkg, golden, seed):
+    """6x6 networks (BASELINE.json configs[4]; reference configs/debug_6x6.yaml = 5x64 on 6x6): the exact-fp32 MFMA
+    trunk vs the reference's own (N,37) / (N,1) outputs (g7), tolerance 1e-4."""
+    g = golden("g7_net6.npz")
+    xd = torch.from_numpy(g["x"]).cuda()
+    for nb, nf in NETS6:
+        tag = "s%d_%dx%d" % (seed, nb, nf)
+        torch.manual_seed(seed)
+        net = pkg.OthelloResNet(nb, nf, board_size=6).eval()
+        if (nb, nf) == (2, 16):
+            net.load_state_dict({k: torch.from_numpy(g[tag + "_sd_" + k]) for k in net.state_dict()})
+        ev = pkg.HipResNetEvaluator(net)
+        assert ev.precision == "f32" and ev.policy_size == 37
+        logp, v = ev.forward_planes(xd)
+        assert tuple(logp.shape) == (len(xd), 37)
+        e1 = np.abs(logp.cpu().numpy() - g[tag + "_logp"]).max()
+        e2 = np.abs(v.cpu().numpy() - g[tag + "_v"]).max()
+        assert e1 < 1e-4 and e2 < 1e-4, (tag, e1, e2)
+
+
+@pytest.mark.parametrize("nb,nf,bs", [(2, 16, 8), (2, 32, 8), (5, 64, 8), (2, 128, 8), (5, 64, 6), (2, 16, 6),
+                                      (2, 32, 6), (2, 128, 6)])
+def test_f32_mfma_trunk_ragged_batches(pkg, nb, nf, bs):
+    """The exact-fp32 MFMA trunk (net_f32.hip) at batch sizes that leave waves, workgroups and tiles partly empty,
+    plus a 3000-position batch, vs torch fp32 on the same weights; and a device-side batch length (n_valid)."""
+    torch.manual_seed(1000 + nf + bs)
+    net = pkg.OthelloResNet(nb, nf, board_size=bs).eval()
+    g = torch.Generator().manual_seed(7)
+    for mod in net.modules():   # trained-like BatchNorm statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    ev = pkg.HipResNetEvaluator(net, precision="f32")
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n in (1, 2, 3, 5, 7, 8, 9, 17, 33, 3000):
+        occ = rng.random((n, bs, bs)) < 0.6
+        own = occ & (rng.random((n, bs, bs)) < 0.5)
+        x = np.stack([own, occ & ~own, (~occ) & (rng.random((n, bs, bs)) < 0.5)], axis=1).astype(np.float32)
+        logp, v = ev.forward_planes(torch.from_numpy(x).cuda())
+        with torch.no_grad():
+            rl, rv = net(torch.from_numpy(x))
+        e1 = (logp.cpu() - rl).abs().max().item()
+        e2 = (v.cpu() - rv).abs().max().item()
+        assert e1 < 1e-4 and e2 < 1e-4, (n, e1, e2)
+    # device-side batch length: rows beyond *n_valid are not evaluated (left untouched)
+    n, nvalid = 64, 37
+    w = (np.uint64(1) << np.arange(bs * bs, dtype=U64))
+    sb = (x[:n, 0].reshape(n, -1).astype(U64) * w).sum(1, dtype=U64)
+    ob = (x[:n, 1].reshape(n, -1).astype(U64) * w).sum(1, dtype=U64)
+    lg = (x[:n, 2].reshape(n, -1).astype(U64) * w).sum(1, dtype=U64)
+    logp2 = torch.full((n, bs * bs + 1), 7.0, device="cuda")
+    v2 = torch.full((n,), 7.0, device="cuda")
+    nv = torch.tensor([nvalid], dtype=torch.int32, device="cuda")
+    dsb, dob, dlg = dev_u64(sb), dev_u64(ob), dev_u64(lg)
+    pkg._lib.call("oth_net_forward_bits", ev.handle, dsb.data_ptr(), dob.data_ptr(), dlg.data_ptr(), n,
+                  nv.data_ptr(), logp2.data_ptr(), v2.data_ptr(), pkg._lib.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(logp2[:nvalid], logp[:nvalid]) and torch.equal(v2[:nvalid], v[:nvalid, 0])
+    assert bool((logp2[nvalid:] == 7.0).all()) and bool((v2[nvalid:] == 7.0).all())
+
+
 def test_net_large_batch_and_ragged_tail(pkg):
     """4096+3 real positions on the 10x128 network: fp32-equivalent MFMA trunk vs torch fp32 on the
     same weights (tolerance 1e-4), every row; batch sizes that are not a multiple of the tile."""
