@@ -230,6 +230,14 @@ int oth_engine_net_spans(oth_engine *e, double *spans, int64_t capacity, int64_t
 int oth_augment_symmetries(const float *states, const float *pis, const float *zs, int64_t n, float *states_out,
                            float *pis_out, float *zs_out, void *stream);
 
+/* ReplayBuffer.sample's minibatch assembly (src/train/buffer.py:59-100: random.sample + np.array over the tuples)
+ * as a device gather: out row i = ring row (ring_start + idx[i]) % ring_size (ring_size = 0: row idx[i]).
+ * states [cap,3,8,8], pis [cap,65], zs [cap] -> states_out [n,3,8,8], pis_out [n,65], values_out [n] (the caller
+ * views it as [n,1], buffer.py:83).  idx: int64 [n].  all DEVICE. */
+int oth_replay_gather(const float *states, const float *pis, const float *zs, const int64_t *idx, int64_t n,
+                      int64_t ring_start, int64_t ring_size, float *states_out, float *pis_out, float *values_out,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,15 +2,16 @@
 """Build the REFERENCE's own Cython bitboard into oracle/_ref/ (test infrastructure only).
 
 The sources stay where they lie under /root/reference (src/cython/bitboard.pyx + .pxd); only
-build outputs land in oracle/_ref/, which is git-ignored; the generated C file is deleted again once the
-extension module is compiled, so that only machine code is kept (and travels to the GPU box).  Compile directives follow the reference's own recipe (/root/reference/setup.py:22-30:
+build outputs land in oracle/_ref/, which is git-ignored AND listed in .gpurunignore: the compiled reference
+module never leaves this container (the reference cannot travel in any form).  The generated C file is deleted
+again once the extension module is compiled, so that only machine code is kept.  Compile directives follow the reference's own recipe (/root/reference/setup.py:22-30:
 -O3, language_level 3, boundscheck/wraparound off, cdivision on).
 
 Nothing in the product path (othello_reinforcement_learning_test_amd/) imports this.  Used by
   * tests/golden/make_golden.py  -- to generate the committed golden vectors, and
   * tests (CPU suite)            -- optional live cross-check of the C restatement.
-On the GPU box /root/reference does not exist; this script then does nothing and the prebuilt
-module (if it travelled with the snapshot) is simply left as it is.
+On the GPU box neither /root/reference nor oracle/_ref exists; this script then does nothing and the tests that
+cross-check against the live reference skip themselves (the committed golden vectors carry its answers).
 """
 import os
 import subprocess

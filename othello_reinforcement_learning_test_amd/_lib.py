@@ -87,6 +87,7 @@ _SIGS = {
     "oth_engine_kernel_time": (C.c_int, [vp, f64p, i64p, f64p, i64p]),
     "oth_engine_set_timing": (C.c_int, [vp, C.c_int32]),
     "oth_engine_net_spans": (C.c_int, [vp, f64p, C.c_int64, i64p]),
+    "oth_replay_gather": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "oth_augment_symmetries": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
 }
 _PLAIN_INT = {"oth_device_available", "oth_net_policy_size", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}

@@ -45,9 +45,54 @@ __global__ __launch_bounds__(256) void k_symmetries(const float* __restrict__ st
     }
 }
 
+// ReplayBuffer.sample (buffer.py:59-100) on the device: the minibatch is a gather of ring rows by index.
+// One wave per sampled row: 768 B + 260 B + 4 B read and written as coalesced 256-byte segments; HBM-bound
+// (2 x 1 032 B per row).  ring_size > 0: idx[i] is the LOGICAL position (0 = oldest) and the ring row is
+// (start + idx[i]) % ring_size, so the caller samples without knowing where the ring currently starts.
+__global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__ st, const float* __restrict__ pi,
+                                                       const float* __restrict__ z, const int64_t* __restrict__ idx,
+                                                       int64_t n, int64_t start, int64_t ring_size,
+                                                       float* __restrict__ st_o, float* __restrict__ pi_o,
+                                                       float* __restrict__ z_o) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t o = w; o < n; o += nw) {
+        int64_t i = idx[o];
+        if (ring_size > 0) i = (start + i) % ring_size;
+        const float* s = st + i * 192;
+        float* d = st_o + o * 192;
+        d[lane] = s[lane];
+        d[64 + lane] = s[64 + lane];
+        d[128 + lane] = s[128 + lane];
+        pi_o[o * 65 + lane] = pi[i * 65 + lane];
+        if (lane == 0) {
+            pi_o[o * 65 + 64] = pi[i * 65 + 64];
+            z_o[o] = z[i];
+        }
+    }
+}
+
 }  // namespace oth
 
 using namespace oth;
+
+extern "C" int oth_replay_gather(const float* states, const float* pis, const float* zs, const int64_t* idx, int64_t n,
+                                 int64_t ring_start, int64_t ring_size, float* states_out, float* pis_out,
+                                 float* values_out, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(n >= 0 && ring_size >= 0 && ring_start >= 0 &&
+                  (n == 0 || (states && pis && zs && idx && states_out && pis_out && values_out)),
+              "oth_replay_gather: null pointer or negative size");
+    if (n == 0) return OTH_OK;
+    OTH_BIND_PTR(states);
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), states, pis, zs, idx, n,
+                       ring_start, ring_size, states_out, pis_out, values_out);
+    OTH_HIP(hipGetLastError());
+    return OTH_OK;
+}
 
 extern "C" int oth_augment_symmetries(const float* states, const float* pis, const float* zs, int64_t n,
                                       float* states_out, float* pis_out, float* zs_out, void* stream) {

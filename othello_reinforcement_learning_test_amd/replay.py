@@ -8,6 +8,9 @@
   storage on the device: FIFO ring of ``(state, pi, z)`` rows, uniform sampling without replacement,
   same exceptions and return shapes, so tuples never round-trip through host lists.  Pure torch
   tensor plumbing (works on CPU tensors too, which is how the CPU tests exercise it).
+* ``train_step`` / ``train_epochs`` -- the trainer's optimisation step (trainer.py:243-367: policy cross-entropy on
+  log-probabilities + value MSE, optional AMP) fed straight from the device ring, so a sampled minibatch never
+  becomes a numpy array.
 * ``load_checkpoint_model``   -- reads a trainer checkpoint (trainer.py:375-384) and rebuilds the
   network, inferring blocks/filters from the key names as players.py:186-202 does.
 """
@@ -75,6 +78,9 @@ class DeviceReplayBuffer:
         self._head = 0
         self._size = 0
 
+    def add_single(self, state, policy, value):  # buffer.py:48-57
+        self.add([(np.asarray(state, dtype=np.float32), np.asarray(policy, dtype=np.float32), float(value))])
+
     def add(self, training_data):
         import torch
         if isinstance(training_data, (list,)):
@@ -109,11 +115,20 @@ class DeviceReplayBuffer:
     def sample(self, batch_size):
         """-> (states (B,3,8,8), policies (B,65), values (B,1)) tensors on the buffer's device."""
         import torch
-        if batch_size > self._size:
-            raise ValueError(f"バッファサイズ ({self._size}) がバッチサイズ ({batch_size}) より小さいです")
-        pick = torch.randperm(self._size, device=self.device)[:batch_size]
-        idx = self._logical_index(pick)
-        return self.states[idx], self.policies[idx], self.values[idx].reshape(-1, 1)
+        if self._size < batch_size:   # buffer.py:72-75
+            raise ValueError(f"Buffer size ({self._size}) is smaller than batch size ({batch_size})")
+        pick = torch.randperm(self._size, device=self.device)[:batch_size]   # uniform, without replacement (buffer.py:78)
+        if self.device.type != "cuda":   # CPU tensors (the host-side tests): plain indexing
+            idx = self._logical_index(pick)
+            return self.states[idx], self.policies[idx], self.values[idx].reshape(-1, 1)
+        st = torch.empty((batch_size, 3, 8, 8), dtype=torch.float32, device=self.device)
+        pi = torch.empty((batch_size, 65), dtype=torch.float32, device=self.device)
+        v = torch.empty((batch_size,), dtype=torch.float32, device=self.device)
+        start = (self._head - self._size) % self.max_size
+        _lib.call("oth_replay_gather", self.states.data_ptr(), self.policies.data_ptr(), self.values.data_ptr(),
+                  pick.data_ptr(), int(batch_size), int(start), int(self.max_size), st.data_ptr(), pi.data_ptr(),
+                  v.data_ptr(), _lib.current_stream())
+        return st, pi, v.reshape(-1, 1)
 
     def ordered(self):
         """All items oldest-first (for tests / checkpoints)."""
@@ -121,15 +136,59 @@ class DeviceReplayBuffer:
         idx = self._logical_index(torch.arange(self._size, device=self.device))
         return self.states[idx], self.policies[idx], self.values[idx]
 
-    def get_statistics(self):  # buffer.py:107-136
+    def get_statistics(self):  # buffer.py:107-136: same keys (trainer.py:210-211 reads value_mean / value_std)
         if self._size == 0:
-            return {"size": 0, "capacity": self.max_size, "usage": 0.0}
+            return {"size": 0, "max_size": self.max_size, "fill_rate": 0.0, "value_mean": 0.0, "value_std": 0.0}
         _, _, v = self.ordered()
         return {
-            "size": self._size, "capacity": self.max_size, "usage": self._size / self.max_size,
-            "value_mean": float(v.mean()), "value_std": float(v.std(unbiased=False)),
-            "value_min": float(v.min()), "value_max": float(v.max()),
+            "size": self._size, "max_size": self.max_size, "fill_rate": self._size / self.max_size,
+            "value_mean": float(v.mean()), "value_std": float(v.std(unbiased=False)),   # np.std: population std
+            "value_min": float(v.min()), "value_max": float(v.max()),                   # extras
         }
+
+
+def policy_loss(policy_logits, target_policies):
+    """trainer.py:330-346: -mean(sum(target * log_probs, dim=1)) (the network already outputs log-softmax)."""
+    import torch
+    return -torch.mean(torch.sum(target_policies * policy_logits, dim=1))
+
+
+def value_loss(value_pred, target_values):
+    """trainer.py:348-363: MSE."""
+    import torch
+    return torch.nn.functional.mse_loss(value_pred, target_values)
+
+
+def train_step(model, optimizer, states, target_policies, target_values, scaler=None):
+    """trainer.py:283-328: one optimisation step on a minibatch of tensors already on the model's device;
+    AMP when a GradScaler is given and the tensors are on the GPU.  Returns the total loss as a float."""
+    import torch
+    optimizer.zero_grad()
+    if scaler is not None and states.is_cuda:
+        with torch.amp.autocast("cuda"):
+            logp, v = model(states)
+            total = policy_loss(logp, target_policies) + value_loss(v, target_values)
+        scaler.scale(total).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        logp, v = model(states)
+        total = policy_loss(logp, target_policies) + value_loss(v, target_values)
+        total.backward()
+        optimizer.step()
+    return total.item()
+
+
+def train_epochs(model, optimizer, buffer, num_epochs, batch_size, scaler=None):
+    """trainer.py:243-280 with the minibatches gathered on the device (no numpy round trip): model.train(), one
+    sampled minibatch per epoch, mean loss.  The model must live on the buffer's device."""
+    model.train()
+    total, batches = 0.0, 0
+    for _ in range(num_epochs):
+        states, target_policies, target_values = buffer.sample(batch_size)
+        total += train_step(model, optimizer, states, target_policies, target_values, scaler)
+        batches += 1
+    return total / batches
 
 
 def infer_architecture(state_dict):

@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -10,9 +12,49 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Multi-rank rehearsal of bench.py's N>1 path (tests/test_gpu_multirank.py): two ranks sharing GPU 0 over gloo.
+# The children must be started BEFORE this process touches the GPU (a GPU-initialised process must not fork+exec on
+# this pool), so they are launched here, at session start of a `-m gpu` run, and the test only collects the result.
+REHEARSAL = {"proc": None, "out": None, "err": None}
+
+
+def _wants_gpu(config):
+    expr = (config.getoption("markexpr") or "").strip()
+    return "gpu" in expr and "not gpu" not in expr
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    if not _wants_gpu(session.config) or os.environ.get("OTHELLO_NO_REHEARSAL"):
+        return
+    out = tempfile.NamedTemporaryFile("w+", suffix=".json", delete=False)
+    err = tempfile.NamedTemporaryFile("w+", suffix=".err", delete=False)
+    env = dict(os.environ)
+    env.update({"OTHELLO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "64", "--step-games", "32", "--sims", "6",
+           "--blocks", "2", "--filters", "16", "--stagger", "8", "--profile-steps", "1", "--no-cpu-baseline"]
+    REHEARSAL["proc"] = subprocess.Popen(cmd, stdout=out, stderr=err, env=env, cwd=ROOT)
+    REHEARSAL["out"], REHEARSAL["err"] = out.name, err.name
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = REHEARSAL["proc"]
+    if p is not None and p.poll() is None:   # never leave ranks behind
+        p.terminate()
+        try:
+            p.wait(timeout=20)
+        except Exception:
+            p.kill()
+
+
+@pytest.fixture(scope="session")
+def rehearsal():
+    return REHEARSAL
 
 
 @pytest.fixture(scope="session")

@@ -622,6 +622,24 @@ def test_device_replay_buffer_from_engine(pkg):
     o_s, o_p, o_z = buf.ordered()
     k = len(buf)
     assert np.array_equal(o_s.cpu().numpy(), hs[n - k:]) and np.array_equal(o_z.cpu().numpy(), hz[n - k:])
+    # the minibatch gather kernel (oth_replay_gather) == indexing the ring, also after the ring has wrapped
+    buf.add((st[:300], pi[:300], z[:300]))
+    o_s, o_p, o_z = buf.ordered()
+    torch.manual_seed(9)
+    s, p, v = buf.sample(128)
+    torch.manual_seed(9)
+    pick = torch.randperm(len(buf), device="cuda")[:128]
+    assert torch.equal(s, o_s[pick]) and torch.equal(p, o_p[pick]) and torch.equal(v[:, 0], o_z[pick])
+    s, p, v = buf.sample(len(buf))      # without replacement: a permutation of the whole ring
+    assert torch.equal(torch.sort(v[:, 0]).values, torch.sort(o_z).values)
+    assert abs(float(p.sum()) - float(o_p.sum())) < 1e-2
+    # trainer-side feed: a few optimisation steps straight from the device ring (trainer.py:243-328)
+    from othello_reinforcement_learning_test_amd.replay import train_epochs
+    model = pkg.OthelloResNet(2, 16).cuda()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    l0 = train_epochs(model, opt, buf, num_epochs=2, batch_size=64)
+    l1 = train_epochs(model, opt, buf, num_epochs=20, batch_size=64)
+    assert np.isfinite(l0) and l1 < l0
 
 
 def test_batched_arena_equals_sequential(pkg):
@@ -794,10 +812,12 @@ def test_selfplay_full_size_properties(pkg):
         _check_replay_consistency(pkg, st[a:a + L], pi[a:a + L], z[a:a + L], np.array([L]), 15, onehot_late=False)
 
 
-def test_no_device_memory_growth(pkg):
+def test_no_device_memory_growth(pkg, rehearsal):
     """Repeated runs of different sizes on one engine, plus engine / evaluator create-destroy cycles, must not
     leak device memory (hipMemGetInfo before and after; the library allocates with hipMalloc, outside torch's
     caching allocator)."""
+    if rehearsal["proc"] is not None:   # the two-rank rehearsal shares this GPU: device-wide free memory moves with it
+        rehearsal["proc"].wait(timeout=900)
     torch.manual_seed(2)
     net = pkg.OthelloResNet(2, 16).eval()
     w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=5, temperature_threshold=6,
