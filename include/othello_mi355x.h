@@ -74,6 +74,27 @@ int oth_tensor_input_batch(const uint64_t *self_b, const uint64_t *opp_b, float 
 /* rules checksum over the LCG position stream of tests/golden (size-independent parity property) */
 int oth_rules_checksum(int64_t n, uint64_t *legal_acc /*HOST*/, uint64_t *flip_acc /*HOST*/, void *stream);
 
+/* ---- board size 6 (BASELINE configs[4]; reference configs/debug_6x6.yaml) -------------------------------------
+ * The `_n` forms take board_size = 8 or 6.  8 is the reference's game (identical to the functions above).  6 is the
+ * SAME algorithm on a 6x6 grid: bit i = row*6 + col, pass action 36, 37-entry policies, planes [3,6,6]; the eight
+ * ray directions and the reference's post-shift edge masks are carried over (bitboard.pyx:20-38 with N = 6).  The
+ * reference itself has no 6x6 rules (its game.size is never read), so 6x6 results are PARITY UNPINNED: they are
+ * checked against the 6x6 build of the CPU oracle, not against the reference. */
+void oth_board_reset_n(int board_size, oth_board *b);
+uint64_t oth_legal_moves_n(int board_size, uint64_t self_board, uint64_t opp_board);
+uint64_t oth_flip_bits_n(int board_size, int pos, uint64_t self_board, uint64_t opp_board);
+int oth_board_make_move_n(int board_size, oth_board *b, int pos);
+int oth_board_is_terminal_n(int board_size, const oth_board *b);
+int oth_legal_moves_batch_n(int board_size, const uint64_t *self_b, const uint64_t *opp_b, uint64_t *legal, int64_t n,
+                            void *stream);
+int oth_make_move_batch_n(int board_size, uint64_t *self_b, uint64_t *opp_b, const int32_t *pos, int32_t *ok,
+                          uint64_t *flips, int64_t n, void *stream);
+int oth_status_batch_n(int board_size, const uint64_t *self_b, const uint64_t *opp_b, int32_t *terminal, int32_t *winner,
+                       int64_t n, void *stream);
+int oth_tensor_input_batch_n(int board_size, const uint64_t *self_b, const uint64_t *opp_b, float *out, int64_t n,
+                             void *stream);
+int oth_rules_checksum_n(int board_size, int64_t n, uint64_t *legal_acc /*HOST*/, uint64_t *flip_acc /*HOST*/, void *stream);
+
 /* =============================================================================================
  * 3. Evaluator: OthelloResNet forward (src/model/net.py:139-205), eval mode
  * =========================================================================================== */
@@ -130,6 +151,9 @@ typedef struct {
                                   position, reused bit-identically within a run (cleared at every run start);
                                   skips re-evaluating positions the search has already evaluated (no reference
                                   counterpart: the reference re-evaluates; outputs are identical) */
+    int32_t board_size;        /* 0 or 8: the reference's 8x8 game.  6: the same engine on a 6x6 board (BASELINE
+                                  configs[4]): pass action 36, policies of 37, states [3,6,6]; rules as oth_*_n(6, ...)
+                                  define them -- PARITY UNPINNED, the reference has no 6x6 rules */
 } oth_engine_cfg;
 
 oth_engine *oth_engine_create(const oth_engine_cfg *cfg);

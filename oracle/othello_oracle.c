@@ -18,11 +18,32 @@
 
 /* pyx:20 DIRECTIONS, pyx:24-38 masks.  The A/H masks are applied AFTER the shift, so the col-1
  * rays die on landing in file A... exactly as the reference computes it. */
-static const int ORC_DIRS[8] = {-8, 8, -1, 1, -9, -7, 7, 9};
+/* Board size: ORC_N = 8 is the reference (everything pinned by the goldens).  ORC_N = 6 builds the same
+ * algorithm on a 6x6 grid as libothello_oracle6.so -- bit i = row*6 + col, pass action 36, the same eight
+ * directions (-N, +N, -1, +1, -(N+1), -(N-1), +(N-1), +(N+1)) with the reference's post-shift masks carried over
+ * (col 0 cleared where the reference clears file A, col N-1 where it clears file H; bits >= N*N never survive).
+ * The reference implements NO 6x6 rules (its `game.size` is never read), so the 6x6 build has nothing to be
+ * pinned against: PARITY UNPINNED.  It exists to check the HIP engine's 6x6 kernel path (BASELINE configs[4]). */
+#ifndef ORC_N
+#define ORC_N 8
+#endif
+#define ORC_CELLS (ORC_N * ORC_N)
+#define ORC_NPOL (ORC_CELLS + 1)
+#define ORC_PLANES (3 * ORC_CELLS)
+static const int ORC_DIRS[8] = {-ORC_N, ORC_N, -1, 1, -(ORC_N + 1), -(ORC_N - 1), ORC_N - 1, ORC_N + 1};
+#if ORC_N == 8
 #define NOT_A 0xFEFEFEFEFEFEFEFEULL
 #define NOT_H 0x7F7F7F7F7F7F7F7FULL
 #define ALLB 0xFFFFFFFFFFFFFFFFULL
+#elif ORC_N == 6
+#define ALLB 0x0000000FFFFFFFFFULL /* 36 cells */
+#define NOT_A 0x0000000FBEFBEFBEULL /* column 0 cleared in each 6-bit row: 0b111110 x 6 */
+#define NOT_H 0x00000007DF7DF7DFULL /* column 5 cleared:                   0b011111 x 6 */
+#else
+#error "ORC_N must be 8 or 6"
+#endif
 static const uint64_t ORC_MASKS[8] = {ALLB, ALLB, NOT_A, NOT_H, NOT_A, NOT_H, NOT_A, NOT_H};
+int orc_board_size(void) { return ORC_N; }
 
 uint64_t orc_flip_direction(int pos, int direction, uint64_t self_b, uint64_t opp_b, uint64_t mask) {
     /* pyx:86-114: walk one ray from pos; collect opponent stones; keep them only if the first
@@ -54,16 +75,18 @@ uint64_t orc_flip_bits(int pos, uint64_t self_b, uint64_t opp_b) { /* pyx:127-13
 }
 
 uint64_t orc_legal(uint64_t self_b, uint64_t opp_b) { /* pyx:148-158: brute force over empties */
-    uint64_t empty = ~(self_b | opp_b), legal = 0;
-    for (int pos = 0; pos < 64; ++pos)
+    uint64_t empty = ~(self_b | opp_b) & ALLB, legal = 0;
+    for (int pos = 0; pos < ORC_CELLS; ++pos)
         if ((empty >> pos) & 1ULL)
             if (orc_flip_bits(pos, self_b, opp_b) != 0) legal |= 1ULL << pos;
     return legal;
 }
 
 void orc_reset(orc_board *b) { /* pyx:62-69 */
-    b->self_board = (1ULL << 28) | (1ULL << 35);
-    b->opp_board = (1ULL << 27) | (1ULL << 36);
+    /* 8x8: black E4,D5 = bits 28,35; white D4,E5 = bits 27,36 (pyx:64-65); 6x6: the same centre pattern */
+    const int lo = ORC_N / 2 - 1, hi = ORC_N / 2;
+    b->self_board = (1ULL << (lo * ORC_N + hi)) | (1ULL << (hi * ORC_N + lo));
+    b->opp_board = (1ULL << (lo * ORC_N + lo)) | (1ULL << (hi * ORC_N + hi));
     b->move_count = 0;
     b->passed = 0;
 }
@@ -75,7 +98,7 @@ static void swap_players(orc_board *b) { /* pyx:160-164 */
 }
 
 int orc_make_move(orc_board *b, int pos) { /* pyx:209-247 */
-    if (pos == 64) {
+    if (pos == ORC_CELLS) {
         if (orc_legal(b->self_board, b->opp_board) == 0) {
             swap_players(b);
             b->move_count += 1;
@@ -84,7 +107,7 @@ int orc_make_move(orc_board *b, int pos) { /* pyx:209-247 */
         }
         return 0;
     }
-    if (pos < 0 || pos > 63) return 0;
+    if (pos < 0 || pos > ORC_CELLS - 1) return 0;
     uint64_t bit = 1ULL << pos;
     if ((b->self_board | b->opp_board) & bit) return 0;
     uint64_t flip = orc_flip_bits(pos, b->self_board, b->opp_board);
@@ -119,60 +142,62 @@ int orc_winner(const orc_board *b) { /* pyx:274-282: relative to the side to mov
 int orc_legal_list(const orc_board *b, int *out) { /* pyx:177-185: ascending, or [64] */
     uint64_t legal = orc_legal(b->self_board, b->opp_board);
     if (legal == 0) {
-        out[0] = 64;
+        out[0] = ORC_CELLS;
         return 1;
     }
     int n = 0;
-    for (int i = 0; i < 64; ++i)
+    for (int i = 0; i < ORC_CELLS; ++i)
         if ((legal >> i) & 1ULL) out[n++] = i;
     return n;
 }
 
 void orc_tensor(const orc_board *b, float *t) { /* pyx:309-323: own / opp / legal planes */
     uint64_t legal = orc_legal(b->self_board, b->opp_board);
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < ORC_CELLS; ++i) {
         t[i] = ((b->self_board >> i) & 1ULL) ? 1.0f : 0.0f;
-        t[64 + i] = ((b->opp_board >> i) & 1ULL) ? 1.0f : 0.0f;
-        t[128 + i] = ((legal >> i) & 1ULL) ? 1.0f : 0.0f;
+        t[ORC_CELLS + i] = ((b->opp_board >> i) & 1ULL) ? 1.0f : 0.0f;
+        t[2 * ORC_CELLS + i] = ((legal >> i) & 1ULL) ? 1.0f : 0.0f;
     }
 }
 
 /* numpy.rot90(m, k) on an 8x8 (counter-clockwise) and numpy.flip(axis=-1), as used at pyx:351-368 */
 static void rot90_8x8(const float *in, int k, float *out) {
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) {
+    const int N = ORC_N;
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c) {
             int sr, sc; /* out[r][c] = in[sr][sc] */
             switch (k & 3) {
             case 0: sr = r; sc = c; break;
-            case 1: sr = c; sc = 7 - r; break;
-            case 2: sr = 7 - r; sc = 7 - c; break;
-            default: sr = 7 - c; sc = r; break;
+            case 1: sr = c; sc = N - 1 - r; break;
+            case 2: sr = N - 1 - r; sc = N - 1 - c; break;
+            default: sr = N - 1 - c; sc = r; break;
             }
-            out[r * 8 + c] = in[sr * 8 + sc];
+            out[r * N + c] = in[sr * N + sc];
         }
 }
 static void fliplr_8x8(const float *in, float *out) {
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) out[r * 8 + c] = in[r * 8 + 7 - c];
+    const int N = ORC_N;
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c) out[r * N + c] = in[r * N + N - 1 - c];
 }
 
 void orc_symmetries(const orc_board *b, const float *pi, float *states, float *pis) {
     /* pyx:347-370: for k in 0..3: (rot90^k), then (rot90^k followed by left-right flip); the
-     * pass probability pi[64] is copied unchanged. */
-    float t[192], tmp[64];
+     * pass probability pi[ORC_CELLS] is copied unchanged. */
+    float t[ORC_PLANES], tmp[ORC_CELLS];
     orc_tensor(b, t);
     for (int k = 0; k < 4; ++k) {
-        float *s0 = states + (2 * k) * 192, *s1 = states + (2 * k + 1) * 192;
-        float *p0 = pis + (2 * k) * 65, *p1 = pis + (2 * k + 1) * 65;
+        float *s0 = states + (2 * k) * ORC_PLANES, *s1 = states + (2 * k + 1) * ORC_PLANES;
+        float *p0 = pis + (2 * k) * ORC_NPOL, *p1 = pis + (2 * k + 1) * ORC_NPOL;
         for (int ch = 0; ch < 3; ++ch) {
-            rot90_8x8(t + ch * 64, k, s0 + ch * 64);
-            fliplr_8x8(s0 + ch * 64, s1 + ch * 64);
+            rot90_8x8(t + ch * ORC_CELLS, k, s0 + ch * ORC_CELLS);
+            fliplr_8x8(s0 + ch * ORC_CELLS, s1 + ch * ORC_CELLS);
         }
         rot90_8x8(pi, k, p0);
         fliplr_8x8(p0, tmp);
         memcpy(p1, tmp, sizeof(tmp));
-        p0[64] = pi[64];
-        p1[64] = pi[64];
+        p0[ORC_CELLS] = pi[ORC_CELLS];
+        p1[ORC_CELLS] = pi[ORC_CELLS];
     }
 }
 
@@ -181,7 +206,7 @@ void orc_legal_batch(const uint64_t *s, const uint64_t *o, uint64_t *out, int64_
 }
 void orc_flip_batch(const uint64_t *s, const uint64_t *o, const int32_t *pos, uint64_t *out, int64_t n) {
     for (int64_t i = 0; i < n; ++i)
-        out[i] = (pos[i] >= 0 && pos[i] < 64) ? orc_flip_bits(pos[i], s[i], o[i]) : 0;
+        out[i] = (pos[i] >= 0 && pos[i] < ORC_CELLS) ? orc_flip_bits(pos[i], s[i], o[i]) : 0;
 }
 
 /* Same position stream and accumulators as tests/golden/make_golden.py (checksum of checksums). */
@@ -193,7 +218,7 @@ void orc_rules_checksum(int64_t n, uint64_t *legal_acc, uint64_t *flip_acc) {
         x = x * 6364136223846793005ULL + 1442695040888963407ULL; c = x;
         x = x * 6364136223846793005ULL + 1442695040888963407ULL; d = x;
         uint64_t occ = (i & 1) ? (a | (c & d)) : (a & c);
-        uint64_t s = occ & d, o = occ & ~d;
+        uint64_t s = occ & d & ALLB, o = occ & ~d & ALLB;
         uint64_t lb = orc_legal(s, o);
         la = la * 0x100000001B3ULL + lb;
         if (lb) {
@@ -210,7 +235,7 @@ void orc_rules_checksum(int64_t n, uint64_t *legal_acc, uint64_t *flip_acc) {
  * ========================================================================================== */
 
 /* numpy's float32 add.reduce over a contiguous array (pairwise sum with 8 partial sums), which is
- * what `masked_probs.sum()` at node.py:76 evaluates.  n <= 128 here (n == 65). */
+ * what `masked_probs.sum()` at node.py:76 evaluates.  n <= 128 here (n == ORC_NPOL). */
 static float np_sum_f32(const float *a, int n) {
     if (n < 8) {
         float r = 0.f;
@@ -246,7 +271,7 @@ typedef struct {
     t_node *nodes;
     t_edge *edges;
     int n_nodes, n_edges, cap_nodes, cap_edges;
-    double root_prior[65]; /* root priors after the Dirichlet mix (float64 in the reference) */
+    double root_prior[ORC_NPOL]; /* root priors after the Dirichlet mix (float64 in the reference) */
     /* pending simulation (lock-step form) */
     int *path;
     int path_len;
@@ -256,7 +281,7 @@ typedef struct {
 
 static void tree_init(t_tree *t, int sims) {
     t->cap_nodes = sims + 2;
-    t->cap_edges = (sims + 2) * 60 + 8;
+    t->cap_edges = (sims + 2) * ORC_CELLS + 8;
     t->nodes = (t_node *)malloc(sizeof(t_node) * t->cap_nodes);
     t->edges = (t_edge *)malloc(sizeof(t_edge) * t->cap_edges);
     t->path = (int *)malloc(sizeof(int) * (sims + 4));
@@ -272,14 +297,14 @@ static void tree_free(t_tree *t) {
 
 /* node.py:62-89 expand: masked renormalised priors over the legal actions, children in legal order */
 static int tree_expand(t_tree *t, const orc_board *b, const float *probs65) {
-    int legal[65];
+    int legal[ORC_NPOL];
     int nl = orc_legal_list(b, legal);
-    float masked[65];
+    float masked[ORC_NPOL];
     memset(masked, 0, sizeof(masked));
     for (int i = 0; i < nl; ++i) masked[legal[i]] = probs65[legal[i]];
-    float sum = np_sum_f32(masked, 65);
+    float sum = np_sum_f32(masked, ORC_NPOL);
     if (sum > 0) {
-        for (int i = 0; i < 65; ++i) masked[i] /= sum;
+        for (int i = 0; i < ORC_NPOL; ++i) masked[i] /= sum;
     } else {
         float u = (float)(1.0 / (double)nl); /* python float stored into a float32 array */
         for (int i = 0; i < nl; ++i) masked[legal[i]] = u;
@@ -414,21 +439,21 @@ static void builtin_dirichlet(void *ctx, double alpha, int n, double *out) {
 static int builtin_choice(void *ctx, const float *pi) {
     xo_state *st = (xo_state *)ctx;
     double u = xo_uniform(st), c = 0, tot = 0;
-    for (int i = 0; i < 65; ++i) tot += pi[i];
-    for (int i = 0; i < 65; ++i) {
+    for (int i = 0; i < ORC_NPOL; ++i) tot += pi[i];
+    for (int i = 0; i < ORC_NPOL; ++i) {
         c += pi[i] / tot;
         if (u < c) return i;
     }
-    for (int i = 64; i >= 0; --i)
+    for (int i = ORC_CELLS; i >= 0; --i)
         if (pi[i] > 0) return i;
-    return 64;
+    return ORC_CELLS;
 }
 
 /* mcts.py:210-228: consumes the RNG; the mixed priors are float64 and live on the root only, where
  * the exploration term is identically zero, so selection never reads them. */
 static void tree_root_noise(t_tree *t, const orc_search_cfg *cfg, const orc_rng *rng) {
     t_node *root = &t->nodes[0];
-    double noise[65];
+    double noise[ORC_NPOL];
     rng->dirichlet(rng->ctx, cfg->dirichlet_alpha, root->n_children, noise);
     for (int i = 0; i < root->n_children; ++i) {
         t_edge *e = &t->edges[root->first_edge + i];
@@ -440,7 +465,7 @@ static void tree_root_noise(t_tree *t, const orc_search_cfg *cfg, const orc_rng 
 /* node.py:147-182 get_policy_distribution */
 static void tree_policy(const t_tree *t, double temperature, float *pi65) {
     const t_node *root = &t->nodes[0];
-    memset(pi65, 0, sizeof(float) * 65);
+    memset(pi65, 0, sizeof(float) * ORC_NPOL);
     if (root->n_children == 0) return;
     if (temperature == 0) {
         int best = 0;
@@ -450,7 +475,7 @@ static void tree_policy(const t_tree *t, double temperature, float *pi65) {
         pi65[t->edges[root->first_edge + best].action] = 1.0f;
         return;
     }
-    float counts[65], total;
+    float counts[ORC_NPOL], total;
     for (int i = 0; i < root->n_children; ++i) {
         float c = (float)t->edges[root->first_edge + i].visit_count;
         counts[i] = temperature == 1.0 ? c : powf(c, (float)(1.0 / temperature));
@@ -462,9 +487,9 @@ static void tree_policy(const t_tree *t, double temperature, float *pi65) {
 
 static void tree_root_stats(const t_tree *t, int32_t *visits, double *wsum, double *prior) {
     const t_node *root = &t->nodes[0];
-    if (visits) memset(visits, 0, sizeof(int32_t) * 65);
-    if (wsum) memset(wsum, 0, sizeof(double) * 65);
-    if (prior) memset(prior, 0, sizeof(double) * 65);
+    if (visits) memset(visits, 0, sizeof(int32_t) * ORC_NPOL);
+    if (wsum) memset(wsum, 0, sizeof(double) * ORC_NPOL);
+    if (prior) memset(prior, 0, sizeof(double) * ORC_NPOL);
     for (int i = 0; i < root->n_children; ++i) {
         const t_edge *e = &t->edges[root->first_edge + i];
         if (visits) visits[e->action] = e->visit_count;
@@ -483,7 +508,7 @@ static void default_rng(orc_rng *r, xo_state *st, uint64_t seed) {
 int orc_search(const orc_board *board, const orc_search_cfg *cfg, orc_eval_fn eval, void *ectx,
                const orc_rng *rng, float *pi65, int32_t *visits65, double *wsum65, double *prior65) {
     t_tree t;
-    float probs[65], value;
+    float probs[ORC_NPOL], value;
     orc_rng lr;
     xo_state st;
     if (!rng || !rng->dirichlet) {
@@ -521,7 +546,7 @@ void orc_search_batch(const orc_board *boards, int n, const orc_search_cfg *cfg,
     }
     t_tree *trees = (t_tree *)malloc(sizeof(t_tree) * n);
     uint64_t *sb = (uint64_t *)malloc(sizeof(uint64_t) * n), *ob = (uint64_t *)malloc(sizeof(uint64_t) * n);
-    float *probs = (float *)malloc(sizeof(float) * 65 * n), *vals = (float *)malloc(sizeof(float) * n);
+    float *probs = (float *)malloc(sizeof(float) * ORC_NPOL * n), *vals = (float *)malloc(sizeof(float) * n);
     int *idx = (int *)malloc(sizeof(int) * n);
     for (int i = 0; i < n; ++i) {
         sb[i] = boards[i].self_board;
@@ -530,7 +555,7 @@ void orc_search_batch(const orc_board *boards, int n, const orc_search_cfg *cfg,
     eval(ectx, n, sb, ob, probs, vals); /* parallel_self_play.py:109 */
     for (int i = 0; i < n; ++i) {       /* :111-118 expand then noise, game by game */
         tree_init(&trees[i], cfg->num_simulations);
-        tree_expand(&trees[i], &boards[i], probs + 65 * i);
+        tree_expand(&trees[i], &boards[i], probs + ORC_NPOL * i);
         if (cfg->add_noise) tree_root_noise(&trees[i], cfg, rng);
     }
     for (int s = 0; s < cfg->num_simulations; ++s) { /* :121-161 */
@@ -547,12 +572,12 @@ void orc_search_batch(const orc_board *boards, int n, const orc_search_cfg *cfg,
         }
         if (m > 0) {
             eval(ectx, m, sb, ob, probs, vals); /* :144 one batched call */
-            for (int j = 0; j < m; ++j) tree_finish_leaf(&trees[idx[j]], probs + 65 * j, vals[j]);
+            for (int j = 0; j < m; ++j) tree_finish_leaf(&trees[idx[j]], probs + ORC_NPOL * j, vals[j]);
         }
     }
     for (int i = 0; i < n; ++i) {
-        if (pi) tree_policy(&trees[i], cfg->temperature, pi + 65 * i);
-        if (visits) tree_root_stats(&trees[i], visits + 65 * i, NULL, NULL);
+        if (pi) tree_policy(&trees[i], cfg->temperature, pi + ORC_NPOL * i);
+        if (visits) tree_root_stats(&trees[i], visits + ORC_NPOL * i, NULL, NULL);
         tree_free(&trees[i]);
     }
     free(trees); free(sb); free(ob); free(probs); free(vals); free(idx);
@@ -560,11 +585,11 @@ void orc_search_batch(const orc_board *boards, int n, const orc_search_cfg *cfg,
 
 int orc_best_action(const orc_board *board, int sims, double c_puct, orc_eval_fn eval, void *ectx) {
     /* mcts.py:271-296 */
-    int legal[65];
+    int legal[ORC_NPOL];
     int nl = orc_legal_list(board, legal);
     if (sims < 1) return legal[0];
     orc_search_cfg cfg = {sims, c_puct, 0.3, 0.25, 0.0, 0};
-    float pi[65];
+    float pi[ORC_NPOL];
     orc_search(board, &cfg, eval, ectx, NULL, pi, NULL, NULL, NULL);
     int best = legal[0];
     float bp = pi[best];
@@ -579,12 +604,12 @@ int orc_best_action(const orc_board *board, int sims, double c_puct, orc_eval_fn
 void orc_action_evaluations(const orc_board *board, int sims, double c_puct, orc_eval_fn eval,
                             void *ectx, int32_t *out65) {
     /* mcts.py:315-362: Q of each root child scaled to int((Q+1)*50), clipped to [0,100] */
-    memset(out65, 0, sizeof(int32_t) * 65);
+    memset(out65, 0, sizeof(int32_t) * ORC_NPOL);
     if (sims < 1) return;
     orc_search_cfg cfg = {sims, c_puct, 0.3, 0.25, 1.0, 0};
-    int32_t visits[65];
-    double wsum[65];
-    int legal[65];
+    int32_t visits[ORC_NPOL];
+    double wsum[ORC_NPOL];
+    int legal[ORC_NPOL];
     int nl = orc_legal_list(board, legal);
     orc_search(board, &cfg, eval, ectx, NULL, NULL, visits, wsum, NULL);
     for (int i = 0; i < nl; ++i) {
@@ -600,7 +625,7 @@ void orc_action_evaluations(const orc_board *board, int sims, double c_puct, orc
  * ========================================================================================== */
 static int argmax65(const float *p) { /* np.argmax: first maximum */
     int b = 0;
-    for (int i = 1; i < 65; ++i)
+    for (int i = 1; i < ORC_NPOL; ++i)
         if (p[i] > p[b]) b = i;
     return b;
 }
@@ -630,10 +655,10 @@ int64_t orc_selfplay_serial(const orc_selfplay_cfg *cfg, int num_episodes, orc_e
             double temp = ply < cfg->temperature_threshold ? 1.0 : 0.0; /* :87 */
             orc_search_cfg sc = {cfg->num_simulations, cfg->c_puct, cfg->dirichlet_alpha,
                                  cfg->dirichlet_epsilon, temp, cfg->add_noise};
-            orc_tensor(&b, states + n * 192);                             /* :90 */
-            orc_search(&b, &sc, eval, ectx, rng, pis + n * 65, NULL, NULL, NULL); /* :93-98 */
+            orc_tensor(&b, states + n * ORC_PLANES);                             /* :90 */
+            orc_search(&b, &sc, eval, ectx, rng, pis + n * ORC_NPOL, NULL, NULL, NULL); /* :93-98 */
             player[ply] = (ply % 2 == 0) ? 1 : -1;                        /* :83 */
-            int a = temp == 0 ? argmax65(pis + n * 65) : rng->choice(rng->ctx, pis + n * 65); /* :108-113 */
+            int a = temp == 0 ? argmax65(pis + n * ORC_NPOL) : rng->choice(rng->ctx, pis + n * ORC_NPOL); /* :108-113 */
             if (moves) moves[n] = a;
             orc_make_move(&b, a);
             ++ply;
@@ -656,7 +681,7 @@ int64_t orc_selfplay_serial(const orc_selfplay_cfg *cfg, int num_episodes, orc_e
  *   orc_philox_uniform  key = seed (lo, hi), counter = (game id, ply, 0x2545F491, 0x9E3779B9); the double is
  *                       built from the first two output words as numpy's random_sample does from two 32-bit
  *                       draws: ((a >> 5) * 2^26 + (b >> 6)) / 2^53;
- *   orc_choice_cdf      numpy.random.choice(65, p=pi) given its uniform draw u (numpy/random/mtrand.pyx, choice():
+ *   orc_choice_cdf      numpy.random.choice(ORC_NPOL, p=pi) given its uniform draw u (numpy/random/mtrand.pyx, choice():
  *                       cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(u, side='right')), p = pi as
  *                       float64; pinned against numpy itself in tests/test_oracle_golden.py. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -681,14 +706,14 @@ double orc_philox_uniform(uint64_t seed, uint32_t game_id, uint32_t ply) {
     return ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
 }
 int orc_choice_cdf(const float *pi65, double u) {
-    double cdf[65], c = 0.0;
-    for (int i = 0; i < 65; ++i) { /* np.cumsum of the float64 copy of p: sequential adds */
+    double cdf[ORC_NPOL], c = 0.0;
+    for (int i = 0; i < ORC_NPOL; ++i) { /* np.cumsum of the float64 copy of p: sequential adds */
         c += (double)pi65[i];
         cdf[i] = c;
     }
-    const double last = cdf[64];
+    const double last = cdf[ORC_CELLS];
     int idx = 0; /* searchsorted(u, side='right') = number of entries <= u */
-    while (idx < 65 && cdf[idx] / last <= u) ++idx;
+    while (idx < ORC_NPOL && cdf[idx] / last <= u) ++idx;
     return idx;
 }
 
@@ -735,12 +760,12 @@ static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episo
         orc_board *bd = (orc_board *)malloc(sizeof(orc_board) * bs);
         int *mc = (int *)calloc(bs, sizeof(int)), *fin = (int *)calloc(bs, sizeof(int)),
             *win = (int *)calloc(bs, sizeof(int));
-        float *hs = (float *)malloc(sizeof(float) * 192 * MAXP * bs);
-        float *hp = (float *)malloc(sizeof(float) * 65 * MAXP * bs);
+        float *hs = (float *)malloc(sizeof(float) * ORC_PLANES * MAXP * bs);
+        float *hp = (float *)malloc(sizeof(float) * ORC_NPOL * MAXP * bs);
         int *hpl = (int *)malloc(sizeof(int) * MAXP * bs), *hmv = (int *)malloc(sizeof(int) * MAXP * bs);
         orc_board *act = (orc_board *)malloc(sizeof(orc_board) * bs);
         int *aidx = (int *)malloc(sizeof(int) * bs);
-        float *api = (float *)malloc(sizeof(float) * 65 * bs);
+        float *api = (float *)malloc(sizeof(float) * ORC_NPOL * bs);
         for (int i = 0; i < bs; ++i) orc_reset(&bd[i]);
         for (;;) { /* :347 */
             int m = 0;
@@ -758,15 +783,15 @@ static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episo
                 if (mc[i] >= MAXP) return -1;
                 double temp = mc[i] < cfg->temperature_threshold ? 1.0 : 0.0;
                 int a;
-                if (temp == 0) a = argmax65(api + 65 * j);
+                if (temp == 0) a = argmax65(api + ORC_NPOL * j);
                 else if (use_philox)
-                    a = orc_choice_cdf(api + 65 * j, orc_philox_uniform(philox_seed, (uint32_t)(completed + i), (uint32_t)mc[i]));
-                else a = rng->choice(rng->ctx, api + 65 * j);
-                orc_tensor(&bd[i], hs + ((int64_t)i * MAXP + mc[i]) * 192);
-                memcpy(hp + ((int64_t)i * MAXP + mc[i]) * 65, api + 65 * j, sizeof(float) * 65);
+                    a = orc_choice_cdf(api + ORC_NPOL * j, orc_philox_uniform(philox_seed, (uint32_t)(completed + i), (uint32_t)mc[i]));
+                else a = rng->choice(rng->ctx, api + ORC_NPOL * j);
+                orc_tensor(&bd[i], hs + ((int64_t)i * MAXP + mc[i]) * ORC_PLANES);
+                memcpy(hp + ((int64_t)i * MAXP + mc[i]) * ORC_NPOL, api + ORC_NPOL * j, sizeof(float) * ORC_NPOL);
                 if (late_onehot && temp == 0) {
-                    float *row = hp + ((int64_t)i * MAXP + mc[i]) * 65;
-                    for (int k = 0; k < 65; ++k) row[k] = k == a ? 1.0f : 0.0f;
+                    float *row = hp + ((int64_t)i * MAXP + mc[i]) * ORC_NPOL;
+                    for (int k = 0; k < ORC_NPOL; ++k) row[k] = k == a ? 1.0f : 0.0f;
                 }
                 hpl[i * MAXP + mc[i]] = (mc[i] % 2 == 0) ? 1 : -1;
                 hmv[i * MAXP + mc[i]] = a;
@@ -783,8 +808,8 @@ static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episo
         for (int i = 0; i < bs; ++i)
             for (int p = 0; p < mc[i]; ++p) {
                 if (n >= cap) return -1;
-                memcpy(states + n * 192, hs + ((int64_t)i * MAXP + p) * 192, sizeof(float) * 192);
-                memcpy(pis + n * 65, hp + ((int64_t)i * MAXP + p) * 65, sizeof(float) * 65);
+                memcpy(states + n * ORC_PLANES, hs + ((int64_t)i * MAXP + p) * ORC_PLANES, sizeof(float) * ORC_PLANES);
+                memcpy(pis + n * ORC_NPOL, hp + ((int64_t)i * MAXP + p) * ORC_NPOL, sizeof(float) * ORC_NPOL);
                 zs[n] = (float)(win[i] * hpl[i * MAXP + p]);
                 if (moves) moves[n] = hmv[i * MAXP + p];
                 ++n;
@@ -796,6 +821,7 @@ static int64_t selfplay_parallel_impl(const orc_selfplay_cfg *cfg, int num_episo
     return n;
 }
 
+#if ORC_N == 8 /* the CPU network and the CPU-baseline drivers exist for the reference's 8x8 game only */
 /* ============================================================================================
  * CPU network -- src/model/net.py (eval mode, fp32)
  * ========================================================================================== */
@@ -1079,3 +1105,4 @@ int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg,
     if (games_ended) *games_ended = ended;
     return total;
 }
+#endif /* ORC_N == 8 */

@@ -23,6 +23,7 @@ typedef struct {
     int32_t passed;                 /* bitboard.pxd:28 */
 } orc_board;
 
+int orc_board_size(void); /* 8 (libothello_oracle.so, pinned) or 6 (libothello_oracle6.so, -DORC_N=6: parity unpinned) */
 uint64_t orc_flip_direction(int pos, int direction, uint64_t self_b, uint64_t opp_b, uint64_t mask); /* pyx:71-114 */
 uint64_t orc_flip_bits(int pos, uint64_t self_b, uint64_t opp_b);                                    /* pyx:116-133 */
 uint64_t orc_legal(uint64_t self_b, uint64_t opp_b);                                                 /* pyx:135-158 */

@@ -31,7 +31,7 @@ class EngineCfg(C.Structure):  # oth_engine_cfg
     _fields_ = [("max_games", C.c_int32), ("num_simulations", C.c_int32),
                 ("temperature_threshold", C.c_int32), ("c_puct", C.c_float),
                 ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double),
-                ("store_late_onehot", C.c_int32), ("eval_cache_log2", C.c_int32)]
+                ("store_late_onehot", C.c_int32), ("eval_cache_log2", C.c_int32), ("board_size", C.c_int32)]
 
 
 u64p, f32p, i32p, f64p, i64p = (C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_int32),
@@ -56,6 +56,16 @@ _SIGS = {
     "oth_status_batch": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp]),
     "oth_tensor_input_batch": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "oth_rules_checksum": (C.c_int, [C.c_int64, u64p, u64p, vp]),
+    "oth_board_reset_n": (None, [C.c_int, C.POINTER(Board)]),
+    "oth_legal_moves_n": (C.c_uint64, [C.c_int, C.c_uint64, C.c_uint64]),
+    "oth_flip_bits_n": (C.c_uint64, [C.c_int, C.c_int, C.c_uint64, C.c_uint64]),
+    "oth_board_make_move_n": (C.c_int, [C.c_int, C.POINTER(Board), C.c_int]),
+    "oth_board_is_terminal_n": (C.c_int, [C.c_int, C.POINTER(Board)]),
+    "oth_legal_moves_batch_n": (C.c_int, [C.c_int, vp, vp, vp, C.c_int64, vp]),
+    "oth_make_move_batch_n": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int64, vp]),
+    "oth_status_batch_n": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int64, vp]),
+    "oth_tensor_input_batch_n": (C.c_int, [C.c_int, vp, vp, vp, C.c_int64, vp]),
+    "oth_rules_checksum_n": (C.c_int, [C.c_int, C.c_int64, u64p, u64p, vp]),
     "oth_net_create": (vp, [C.c_int, C.c_int, C.c_int]),
     "oth_net_destroy": (None, [vp]),
     "oth_net_state_floats": (C.c_int64, [vp]),
@@ -90,7 +100,7 @@ _SIGS = {
     "oth_replay_gather": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "oth_augment_symmetries": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
 }
-_PLAIN_INT = {"oth_device_available", "oth_net_policy_size", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}
+_PLAIN_INT = {"oth_device_available", "oth_net_policy_size", "oth_board_make_move_n", "oth_board_is_terminal_n", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}
 
 _lib = None
 

@@ -178,7 +178,7 @@ __device__ __forceinline__ bool cache_fetch(const Dev& d, int g, uint64_t sb, ui
     const uint32_t cs = cache_slot(d, sb, ob);
     if (!(d.ck[2 * (size_t)cs] == sb && d.ck[2 * (size_t)cs + 1] == ob)) return false;
     const float* src = d.cv + (size_t)cs * 66;
-    float* dst = d.cres + (size_t)g * 66;
+    float* dst = d.cres + (size_t)g * 66;   // [0, NPOL) policy, [65] value (row layout shared by both board sizes)
     dst[lane] = src[lane];
     if (lane < 2) dst[64 + lane] = src[64 + lane];
     return true;
@@ -195,30 +195,35 @@ __device__ __forceinline__ void write_eval(const Dev& d, int slot, uint64_t sb, 
 // ---- expand + backup (node.py:62-89, mcts.py:133-148) ---------------------------------------------
 // The pending position of game g (its root, or the leaf chosen by the previous launch) has been evaluated:
 // mask + renormalise the priors, append the node and its edges, link it and back the value up.
+template <int BS>
 __device__ __forceinline__ void expand_pending(const Dev& d, int g, int lane, int pend,
                                                const float* __restrict__ policy, const float* __restrict__ value,
                                                int is_log) {
+    constexpr int CELLS = Geo<BS>::CELLS, NP = Geo<BS>::NPOL;
     const int slot = d.eval_slot[g];
-    const float* pol = slot >= 0 ? policy + (size_t)slot * 65 : d.cres + (size_t)g * 66;
+    const float* pol = slot >= 0 ? policy + (size_t)slot * NP : d.cres + (size_t)g * 66;
     const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g], legal = d.leaf_legal[g];
     const bool pass = legal == 0;
-    float p = pol[lane], p64 = pol[64];
+    float p = lane < CELLS ? pol[lane] : -INFINITY, p64 = pol[CELLS];
     if (is_log) {  // policy_probs = torch.exp(policy_logits), mcts.py:189
         p = expf(p);
         p64 = expf(p64);
     }
-    // masked_probs[legal] = policy_probs[legal] (node.py:71-72); element 64 is the pass action
+    // masked_probs[legal] = policy_probs[legal] (node.py:71-72); element CELLS (64 on 8x8) is the pass action
     const bool act = pass ? false : ((legal >> lane) & 1ULL);
     const float m = act ? p : 0.0f;
     const float m64 = pass ? p64 : 0.0f;
-    // prob_sum = masked_probs.sum(): numpy float32 pairwise reduction over 65 elements, i.e.
-    // r[j] = a[j] + a[8+j] + ... + a[56+j] (in that order), ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), + a[64]
+    // prob_sum = masked_probs.sum(): numpy float32 pairwise reduction over NP elements (65 on 8x8), i.e.
+    // r[j] = a[j] + a[8+j] + ... over the NP/8 full groups of 8 (in that order),
+    // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the NP % 8 trailing elements one by one (8x8: a[64] only)
     float r = m;
 #pragma unroll
-    for (int i = 1; i < 8; ++i) r += __shfl(m, (8 * i + lane) & 63);
+    for (int i = 1; i < NP / 8; ++i) r += __shfl(m, (8 * i + lane) & 63);
     const float r0 = __shfl(r, 0), r1 = __shfl(r, 1), r2 = __shfl(r, 2), r3 = __shfl(r, 3);
     const float r4 = __shfl(r, 4), r5 = __shfl(r, 5), r6 = __shfl(r, 6), r7 = __shfl(r, 7);
     float sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+#pragma unroll
+    for (int i = 8 * (NP / 8); i < CELLS; ++i) sum += __shfl(m, i);
     sum += m64;
     const int nch = pass ? 1 : __popcll(legal);
     float prior;
@@ -245,15 +250,17 @@ __device__ __forceinline__ void expand_pending(const Dev& d, int g, int lane, in
         d.pend[g] = PEND_NONE;
     }
     if (depth > 0) {
-        const double v = (double)(slot >= 0 ? value[slot] : pol[65]);  // values[j].item(): float32 -> python float
+        const double v = (double)(slot >= 0 ? value[slot] : pol[65]);  // values[j].item(): float32 -> python float (cache rows: [65])
         backup_path(edges, path, depth, v, lane, id);
     }
 }
 
 // Insert the fresh network results of the pending positions into the evaluation cache.  Runs as its own
 // launch between the network and k_tree, so no entry is read (cache_fetch, in k_tree) while it is rewritten.
+template <int BS>
 __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __restrict__ policy,
                                                       const float* __restrict__ value) {
+    constexpr int CELLS = Geo<BS>::CELLS, NP = Geo<BS>::NPOL;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= d.n_slots || d.pend[g] == PEND_NONE) return;
@@ -265,9 +272,9 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
     if (lane == 0) own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
     if (!__shfl(own, 0)) return;
     float* dst = d.cv + (size_t)cs * 66;
-    dst[lane] = policy[(size_t)slot * 65 + lane];
+    if (lane < CELLS) dst[lane] = policy[(size_t)slot * NP + lane];
     if (lane == 0) {
-        dst[64] = policy[(size_t)slot * 65 + 64];
+        dst[CELLS] = policy[(size_t)slot * NP + CELLS];
         dst[65] = value[slot];
         d.ck[2 * (size_t)cs] = sb;
         d.ck[2 * (size_t)cs + 1] = ob;
@@ -305,6 +312,7 @@ __device__ __forceinline__ void begin_root(const Dev& d, int g, uint64_t sb, uin
     }
 }
 
+template <int BS>
 __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __restrict__ sb,
                                                       const uint64_t* __restrict__ ob, int n) {
     __shared__ BlockTally bt;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void k_search_begin(Dev d, const uint64_t* __r
         return;
     }
     if (lane == 0) { d.g_active[g] = 1; d.g_self[g] = s0; d.g_opp[g] = o0; }
-    begin_root(d, g, s0, o0, legal_moves(s0, o0), slot, lane);
+    begin_root(d, g, s0, o0, legal_moves_n<BS>(s0, o0), slot, lane);
 }
 
 // all slots idle; slot g < n_start joins (starts game id g) at round g * stagger / n_start (stagger 0: at once)
@@ -346,9 +354,10 @@ __global__ void k_slots_init(Dev d, int n_start, int stagger) {
 //                       the end of the game, refill the slot, queue the next root; idle slots whose join round
 //                       has come start their first game;
 //          TREE_NONE    nothing (last launch of a stand-alone search).
-template <int MODE>
+template <int MODE, int BS>
 __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ policy, const float* __restrict__ value,
                                               int is_log, const int32_t* __restrict__ forced, int refill) {
+    constexpr int CELLS = Geo<BS>::CELLS;
     extern __shared__ uint32_t lds_path_all[];  // [4 waves][cap_path]: the path of the current descent
     __shared__ BlockTally bt;
     const int lane = threadIdx.x & 63;
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
     const bool in_range = g < d.n_slots;
     {
         const int pend = in_range ? d.pend[g] : PEND_NONE;
-        if (pend != PEND_NONE) expand_pending(d, g, lane, pend, policy, value, is_log);
+        if (pend != PEND_NONE) expand_pending<BS>(d, g, lane, pend, policy, value, is_log);
     }
     if constexpr (MODE == TREE_NONE) return;
     // the descent / the ply step below read nodes and edges other lanes of this wave have just written
@@ -398,17 +407,17 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
                 const double best = wave_max_f64(score);
                 const unsigned long long eq = __ballot(act && score == best);
                 const int L = __ffsll(eq) - 1;  // first maximum in insertion order (strict > at node.py:121)
-                const int action = pass ? 64 : L;
+                const int action = pass ? CELLS : L;
                 const int ce = __shfl(ei, L), child = __shfl(e_child, L), nvis = __shfl(e_n, L);
                 if (lane == 0) lpath[depth] = (uint32_t)ce;
                 ++depth;
-                apply_known(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
+                apply_known_n<BS>(sb, ob, action);  // board.make_move(action), parallel_self_play.py:189
                 if (child == 0) break;        // that child has no children yet: leaf
                 pv = nvis;
                 node = child;
             }
-            lg = legal_moves(sb, ob);
-            terminal = lg == 0 && legal_moves(ob, sb) == 0;  // bitboard.pyx:249-264
+            lg = legal_moves_n<BS>(sb, ob);
+            terminal = lg == 0 && legal_moves_n<BS>(ob, sb) == 0;  // bitboard.pyx:249-264
             if (!terminal) cached = cache_fetch(d, g, sb, ob, lane);
             need = !terminal && !cached;
         }
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
             // first maximum of the visit counts (np.argmax)
             const int best_n = max(wave_max_i32(act ? n : -1), pass ? n64 : -1);
             const unsigned long long eqm = __ballot(act && n == best_n);
-            const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+            const int amax = pass ? CELLS : (__ffsll(eqm) - 1);
             const int ply = d.g_ply[g];
             gid = d.g_id[g];
             const bool sample = ply < d.temp_threshold;
@@ -458,21 +467,21 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
             } else if (!sample) {
                 action = amax;
             } else {
-                // np.random.choice(65, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
+                // np.random.choice(NP, p=pi): cdf = cumsum(p as float64); cdf /= cdf[-1]; searchsorted(u, 'right')
                 const double u = philox_uniform(d.seed, (uint32_t)gid, (uint32_t)ply);
                 double c = 0.0;
                 double cdf_lane = 0.0;
-                for (int i = 0; i < 64; ++i) {  // sequential cumsum, every lane runs it identically
+                for (int i = 0; i < CELLS; ++i) {  // sequential cumsum, every lane runs it identically
                     c += (double)__shfl(pi, i);
                     if (i == lane) cdf_lane = c;
                 }
                 const double c64 = c + (double)pi64;
-                const unsigned long long gt = __ballot(cdf_lane / c64 > u);
-                action = gt ? (__ffsll(gt) - 1) : 64;
+                const unsigned long long gt = __ballot(lane < CELLS && cdf_lane / c64 > u);
+                action = gt ? (__ffsll(gt) - 1) : CELLS;
             }
             if (d.store_late_onehot && !sample) {  // SelfPlayWorker stores the T=0 one-hot (self_play.py:87-105)
                 pi = (lane == amax) ? 1.0f : 0.0f;
-                pi64 = (amax == 64) ? 1.0f : 0.0f;
+                pi64 = (amax == CELLS) ? 1.0f : 0.0f;
             }
             // record the sample: position bits (state planes are unpacked at compaction) and pi
             sb = d.g_self[g];
@@ -480,18 +489,18 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
             const size_t hidx = (size_t)(gid & d.hist_mask);
             {
                 const size_t h = hidx * kMaxPly + ply;
-                float* hp = d.hist_pi + h * 65;
-                hp[lane] = pi;
+                float* hp = d.hist_pi + h * 65;   // rows keep the 8x8 stride; NP entries are used
+                if (lane < CELLS) hp[lane] = pi;
                 if (lane == 0) {
-                    hp[64] = pi64;
+                    hp[CELLS] = pi64;
                     d.hist_bits[h * 3 + 0] = sb;
                     d.hist_bits[h * 3 + 1] = ob;
                     d.hist_bits[h * 3 + 2] = root.legal;
                 }
             }
-            apply_known(sb, ob, action);  // game.board.make_move(action)
+            apply_known_n<BS>(sb, ob, action);  // game.board.make_move(action)
             nply = ply + 1;
-            over = is_terminal(sb, ob) || nply >= kMaxPly;
+            over = is_terminal_n<BS>(sb, ob) || nply >= kMaxPly;
             if (over) {
                 int new_id = -1;
                 if (lane == 0) {
@@ -510,8 +519,8 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
                 if (new_id >= 0) {
                     gid = new_id;
                     nply = 0;
-                    sb = kStartSelf;
-                    ob = kStartOpp;
+                    sb = Geo<BS>::start_self();
+                    ob = Geo<BS>::start_opp();
                     next_root = true;
                     if (lane == 0) d.game_len[gid & d.hist_mask] = 0;
                 }
@@ -521,8 +530,8 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
         } else if (in_range && d.g_join[g] == d.round && g < d.game_limit) {  // first game of this slot: id = slot
             gid = g;
             nply = 0;
-            sb = kStartSelf;
-            ob = kStartOpp;
+            sb = Geo<BS>::start_self();
+            ob = Geo<BS>::start_opp();
             next_root = joined = true;
             if (lane == 0) {
                 d.game_len[gid & d.hist_mask] = 0;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
         if (cached) slot = kCachedSlot;
         if (next_root) {
             if (lane == 0) { d.g_id[g] = gid; d.g_self[g] = sb; d.g_opp[g] = ob; d.g_ply[g] = nply; }
-            begin_root(d, g, sb, ob, legal_moves(sb, ob), slot, lane);
+            begin_root(d, g, sb, ob, legal_moves_n<BS>(sb, ob), slot, lane);
         } else if (lane == 0) {
             d.g_active[g] = 0;
             d.g_id[g] = -1;
@@ -547,9 +556,11 @@ __global__ __launch_bounds__(256) void k_tree(Dev d, const float* __restrict__ p
 }
 
 // ---- search results (node.py:147-182 + root statistics) ------------------------------------------
+template <int BS>
 __global__ __launch_bounds__(256) void k_results(Dev d, int n, int temp_zero, float* __restrict__ pi_out,
                                                  int32_t* __restrict__ visits, double* __restrict__ wsum,
                                                  float* __restrict__ prior) {
+    constexpr int CELLS = Geo<BS>::CELLS, NP = Geo<BS>::NPOL;
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n) return;
@@ -566,19 +577,20 @@ __global__ __launch_bounds__(256) void k_results(Dev d, int n, int temp_zero, fl
     if (temp_zero) {
         const int best_n = max(wave_max_i32(act ? (int)e.n : -1), pass ? (int)e64.n : -1);
         const unsigned long long eqm = __ballot(act && (int)e.n == best_n);
-        const int amax = pass ? 64 : (__ffsll(eqm) - 1);
+        const int amax = pass ? CELLS : (__ffsll(eqm) - 1);
         pi = lane == amax ? 1.0f : 0.0f;
-        pi64 = amax == 64 ? 1.0f : 0.0f;
+        pi64 = amax == CELLS ? 1.0f : 0.0f;
     } else {
         const float tf = (float)total;
         pi = act ? (float)e.n / tf : 0.0f;
         pi64 = pass ? (float)e64.n / tf : 0.0f;
     }
-    const size_t o = (size_t)g * 65;
-    if (pi_out) { pi_out[o + lane] = pi; if (lane == 0) pi_out[o + 64] = pi64; }
-    if (visits) { visits[o + lane] = act ? (int)e.n : 0; if (lane == 0) visits[o + 64] = (int)e64.n; }
-    if (wsum) { wsum[o + lane] = act ? e.w : 0.0; if (lane == 0) wsum[o + 64] = e64.w; }
-    if (prior) { prior[o + lane] = act ? e.prior : 0.0f; if (lane == 0) prior[o + 64] = e64.prior; }
+    const size_t o = (size_t)g * NP;
+    const bool sq = lane < CELLS;
+    if (pi_out) { if (sq) pi_out[o + lane] = pi; if (lane == 0) pi_out[o + CELLS] = pi64; }
+    if (visits) { if (sq) visits[o + lane] = act ? (int)e.n : 0; if (lane == 0) visits[o + CELLS] = (int)e64.n; }
+    if (wsum) { if (sq) wsum[o + lane] = act ? e.w : 0.0; if (lane == 0) wsum[o + CELLS] = e64.w; }
+    if (prior) { if (sq) prior[o + lane] = act ? e.prior : 0.0f; if (lane == 0) prior[o + CELLS] = e64.prior; }
 }
 
 // ---- compaction of the replay tuples, game-major then ply (parallel_self_play.py:400-405) --------
@@ -609,12 +621,14 @@ __global__ void k_scan_lengths(const int32_t* __restrict__ len, const int32_t* _
     }
 }
 
+template <int BS>
 __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ hist_bits, const float* __restrict__ hist_pi,
                                                  const int32_t* __restrict__ len_out, const int32_t* __restrict__ win,
                                                  const int32_t* __restrict__ list, int mask,
                                                  const int64_t* __restrict__ off, int num_games,
                                                  float* __restrict__ states, float* __restrict__ pis, float* __restrict__ zs) {
-    // one wave per (game, ply) sample; 768 B + 260 B + 4 B written per sample, coalesced rows
+    // one wave per (game, ply) sample; 768 B + 260 B + 4 B written per sample (8x8), coalesced rows
+    constexpr int CELLS = Geo<BS>::CELLS, NP = Geo<BS>::NPOL;
     const int lane = threadIdx.x & 63;
     const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int gi = (int)(w / kMaxPly), ply = (int)(w % kMaxPly);
@@ -623,13 +637,15 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ hi
     const size_t h = hidx * kMaxPly + ply;
     const int64_t o = off[gi] + ply;
     const uint64_t sb = hist_bits[h * 3], ob = hist_bits[h * 3 + 1], lg = hist_bits[h * 3 + 2];
-    float* st = states + o * 192;
-    st[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;        // get_tensor_input planes (bitboard.pyx:309-323)
-    st[64 + lane] = (ob >> lane) & 1ULL ? 1.0f : 0.0f;
-    st[128 + lane] = (lg >> lane) & 1ULL ? 1.0f : 0.0f;
-    pis[o * 65 + lane] = hist_pi[h * 65 + lane];
+    float* st = states + o * 3 * CELLS;
+    if (lane < CELLS) {
+        st[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;        // get_tensor_input planes (bitboard.pyx:309-323)
+        st[CELLS + lane] = (ob >> lane) & 1ULL ? 1.0f : 0.0f;
+        st[2 * CELLS + lane] = (lg >> lane) & 1ULL ? 1.0f : 0.0f;
+        pis[o * NP + lane] = hist_pi[h * 65 + lane];
+    }
     if (lane == 0) {
-        pis[o * 65 + 64] = hist_pi[h * 65 + 64];
+        pis[o * NP + CELLS] = hist_pi[h * 65 + CELLS];
         const int player = (ply & 1) ? -1 : 1;           // parallel_self_play.py:385
         zs[o] = (float)(win[hidx] * player);              // parallel_self_play.py:404
     }
@@ -670,6 +686,9 @@ struct oth_engine {
     int64_t out_cap = 0, n_samples = 0;
     int64_t* d_total = nullptr;
     int device = 0;   // HIP device of every allocation of this engine
+    int board = 8;    // board size: 8 (the reference's game) or 6
+    int cells() const { return board * board; }
+    int npol() const { return board * board + 1; }
     int32_t n_roots = 0;
     int32_t run_games = 0;        // games in the last harvest
     std::vector<int32_t> run_ids; // their ids, in output order
@@ -695,6 +714,18 @@ struct oth_engine {
 };
 
 static inline int blocks_for(int n_slots) { return (n_slots + 3) / 4; }
+
+// run a statement with BS = the engine's board size as a compile-time constant (kernels are templates on it)
+#define OTH_DISPATCH_BS(e, ...)              \
+    do {                                     \
+        if ((e)->board == 6) {               \
+            constexpr int BS = 6;            \
+            __VA_ARGS__;                     \
+        } else {                             \
+            constexpr int BS = 8;            \
+            __VA_ARGS__;                     \
+        }                                    \
+    } while (0)
 
 template <typename T>
 static int dev_alloc(oth_engine* e, T** p, size_t count) {
@@ -784,7 +815,8 @@ static int launch_net(oth_engine* e, hipStream_t s) {
     if ((r = span_end(e, s))) return r;
     if (e->d.cmask) {  // insert the fresh results before the next tree launch looks the cache up
         e->d.cepoch += 1;
-        hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.logp, e->d.val);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_cache_insert<BS>), dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d,
+                                              e->d.logp, e->d.val));
         OTH_HIP(hipGetLastError());
     }
     return OTH_OK;
@@ -802,11 +834,14 @@ static int launch_tree(oth_engine* e, int mode, int is_log, const int32_t* force
     const dim3 grid(blocks_for(e->d.n_slots)), block(256);
     const size_t lds = sizeof(uint32_t) * 4 * e->d.cap_path;
     if (mode == TREE_SELECT)
-        hipLaunchKernelGGL(k_tree<TREE_SELECT>, grid, block, lds, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_tree<TREE_SELECT, BS>), grid, block, lds, s, e->d, e->d.logp, e->d.val,
+                                              is_log, forced, refill));
     else if (mode == TREE_PLY)
-        hipLaunchKernelGGL(k_tree<TREE_PLY>, grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_tree<TREE_PLY, BS>), grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log,
+                                              forced, refill));
     else
-        hipLaunchKernelGGL(k_tree<TREE_NONE>, grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log, forced, refill);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_tree<TREE_NONE, BS>), grid, block, 0, s, e->d, e->d.logp, e->d.val, is_log,
+                                              forced, refill));
     OTH_HIP(hipGetLastError());
     return span_end(e, s);
 }
@@ -915,9 +950,9 @@ static int harvest(oth_engine* e, int n, const int32_t* ids, int64_t* n_samples,
     }
     if (total > 0) {
         const int64_t waves = (int64_t)n * kMaxPly;
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, e->d.hist_bits, e->d.hist_pi,
-                           e->d_len_out, e->d.game_winner, dlist, e->d.hist_mask, e->d_off, n, e->out_states,
-                           e->out_pis, e->out_zs);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_compact<BS>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
+                                              e->d.hist_bits, e->d.hist_pi, e->d_len_out, e->d.game_winner, dlist,
+                                              e->d.hist_mask, e->d_off, n, e->out_states, e->out_pis, e->out_zs));
         OTH_HIP(hipGetLastError());
     }
     if (ids && n > 0) {
@@ -998,9 +1033,14 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         set_error("oth_engine_create: need max_games >= 1 and 0 <= num_simulations <= 4000");
         return nullptr;
     }
+    if (!(cfg->board_size == 0 || cfg->board_size == 8 || cfg->board_size == 6)) {
+        set_error("oth_engine_create: board_size must be 8 (or 0 = 8) or 6");
+        return nullptr;
+    }
     oth_engine* e = new oth_engine();
     e->device = current_device();
     e->cfg = *cfg;
+    e->board = cfg->board_size == 6 ? 6 : 8;
     Dev& d = e->d;
     const int G = cfg->max_games, S = cfg->num_simulations;
     d.n_slots = G;
@@ -1082,6 +1122,8 @@ void oth_engine_destroy(oth_engine* e) {
 
 int oth_engine_set_net(oth_engine* e, oth_net* net) {
     OTH_CHECK(e, "oth_engine_set_net: null engine");
+    OTH_CHECK(!net || net->board == e->board, "oth_engine_set_net: the network is built for a %dx%d board, the engine for %dx%d",
+              net ? net->board : 0, net ? net->board : 0, e->board, e->board);
     e->net = net;
     return OTH_OK;
 }
@@ -1103,7 +1145,8 @@ int oth_search_begin(oth_engine* e, const uint64_t* sb, const uint64_t* ob, int3
     if (rc) return rc;
     if ((rc = cache_clear(e, s))) return rc;
     bind_cursor(e);
-    hipLaunchKernelGGL(k_search_begin, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.g_self, e->d.g_opp, n);
+    OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_search_begin<BS>), dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d,
+                                          e->d.g_self, e->d.g_opp, n));
     OTH_HIP(hipGetLastError());
     e->n_roots = n;
     return OTH_OK;
@@ -1143,11 +1186,12 @@ int oth_search_expand(oth_engine* e, const float* policy, const float* value, in
     OTH_HIP(hipMemcpyAsync(&n, filled_cursor(e), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OTH_HIP(hipStreamSynchronize(s));
     if (n > 0) {  // caller memory may be host or device: stage into the engine's own arrays
-        OTH_HIP(hipMemcpyAsync(e->d.logp, policy, sizeof(float) * 65 * n, hipMemcpyDefault, s));
+        OTH_HIP(hipMemcpyAsync(e->d.logp, policy, sizeof(float) * e->npol() * n, hipMemcpyDefault, s));
         OTH_HIP(hipMemcpyAsync(e->d.val, value, sizeof(float) * n, hipMemcpyDefault, s));
         if (e->d.cmask) {
             e->d.cepoch += 1;
-            hipLaunchKernelGGL(k_cache_insert, dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s, e->d, e->d.logp, e->d.val);
+            OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_cache_insert<BS>), dim3(blocks_for(e->d.n_slots)), dim3(256), 0, s,
+                                                  e->d, e->d.logp, e->d.val));
             OTH_HIP(hipGetLastError());
         }
     }
@@ -1175,12 +1219,14 @@ int oth_search_results(oth_engine* e, double temperature, float* pi, int32_t* vi
     float *dpi = e->r_pi, *dpr = e->r_prior;
     int32_t* dv = e->r_visits;
     double* dw = e->r_wsum;
-    hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, temperature == 0.0 ? 1 : 0, dpi, dv, dw, dpr);
+    OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_results<BS>), dim3(blocks_for(n)), dim3(256), 0, s, e->d, n,
+                                          temperature == 0.0 ? 1 : 0, dpi, dv, dw, dpr));
     OTH_HIP(hipGetLastError());
-    if (pi) OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
-    if (visits) OTH_HIP(hipMemcpyAsync(visits, dv, sizeof(int32_t) * 65 * n, hipMemcpyDeviceToHost, s));
-    if (wsum) OTH_HIP(hipMemcpyAsync(wsum, dw, sizeof(double) * 65 * n, hipMemcpyDeviceToHost, s));
-    if (prior) OTH_HIP(hipMemcpyAsync(prior, dpr, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
+    const size_t np = (size_t)e->npol();
+    if (pi) OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * np * n, hipMemcpyDeviceToHost, s));
+    if (visits) OTH_HIP(hipMemcpyAsync(visits, dv, sizeof(int32_t) * np * n, hipMemcpyDeviceToHost, s));
+    if (wsum) OTH_HIP(hipMemcpyAsync(wsum, dw, sizeof(double) * np * n, hipMemcpyDeviceToHost, s));
+    if (prior) OTH_HIP(hipMemcpyAsync(prior, dpr, sizeof(float) * np * n, hipMemcpyDeviceToHost, s));
     OTH_HIP(hipStreamSynchronize(s));
     int rc = read_counters(e, s);
     if (rc) return rc;
@@ -1254,12 +1300,12 @@ int oth_selfplay_search(oth_engine* e, float* pi, int32_t* active, void* stream)
     if (active) OTH_HIP(hipMemcpyAsync(active, e->d.g_active, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     if (pi) {
         float* dpi = e->r_pi;
-        OTH_HIP(hipMemsetAsync(dpi, 0, sizeof(float) * 65 * n, s));
+        OTH_HIP(hipMemsetAsync(dpi, 0, sizeof(float) * e->npol() * n, s));
         // finished games keep a stale tree: their rows are garbage by contract (active[i] == 0)
-        hipLaunchKernelGGL(k_results, dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, 0, dpi, (int32_t*)nullptr,
-                           (double*)nullptr, (float*)nullptr);
+        OTH_DISPATCH_BS(e, hipLaunchKernelGGL((k_results<BS>), dim3(blocks_for(n)), dim3(256), 0, s, e->d, n, 0, dpi,
+                                              (int32_t*)nullptr, (double*)nullptr, (float*)nullptr));
         OTH_HIP(hipGetLastError());
-        OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * 65 * n, hipMemcpyDeviceToHost, s));
+        OTH_HIP(hipMemcpyAsync(pi, dpi, sizeof(float) * e->npol() * n, hipMemcpyDeviceToHost, s));
     }
     OTH_HIP(hipStreamSynchronize(s));
     return OTH_OK;
@@ -1387,8 +1433,8 @@ int oth_selfplay_fetch(oth_engine* e, float* states, float* pis, float* zs, int3
     hipStream_t s = as_stream(stream);
     const int64_t n = e->n_samples;
     if (n > 0) {
-        if (states) OTH_HIP(hipMemcpyAsync(states, e->out_states, (size_t)n * 192 * sizeof(float), hipMemcpyDefault, s));
-        if (pis) OTH_HIP(hipMemcpyAsync(pis, e->out_pis, (size_t)n * 65 * sizeof(float), hipMemcpyDefault, s));
+        if (states) OTH_HIP(hipMemcpyAsync(states, e->out_states, (size_t)n * 3 * e->cells() * sizeof(float), hipMemcpyDefault, s));
+        if (pis) OTH_HIP(hipMemcpyAsync(pis, e->out_pis, (size_t)n * e->npol() * sizeof(float), hipMemcpyDefault, s));
         if (zs) OTH_HIP(hipMemcpyAsync(zs, e->out_zs, (size_t)n * sizeof(float), hipMemcpyDefault, s));
     }
     if (game_len && e->run_games > 0)

@@ -67,20 +67,22 @@ int bind_pointer_device(const void* p) {
 }
 
 // -------------------------------------------------------------------------------- kernels
+template <int N>
 __global__ void k_legal(const uint64_t* __restrict__ s, const uint64_t* __restrict__ o,
                         uint64_t* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = legal_moves(s[i], o[i]);
+        out[i] = legal_moves_n<N>(s[i], o[i]);
 }
 
+template <int N>
 __global__ void k_make_move(uint64_t* __restrict__ s, uint64_t* __restrict__ o, const int32_t* __restrict__ pos,
                             int32_t* __restrict__ ok, uint64_t* __restrict__ flips, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         Board b{s[i], o[i], 0, 0};
         const int p = pos[i];
         uint64_t f = 0;
-        if (p >= 0 && p < 64 && !((b.self_b | b.opp_b) >> p & 1ULL)) f = flip_bits(p, b.self_b, b.opp_b);
-        const int r = make_move(b, p);
+        if (p >= 0 && p < Geo<N>::CELLS && !((b.self_b | b.opp_b) >> p & 1ULL)) f = flip_bits_n<N>(p, b.self_b, b.opp_b);
+        const int r = make_move_n<N>(b, p);
         s[i] = b.self_b;
         o[i] = b.opp_b;
         ok[i] = r;
@@ -88,27 +90,32 @@ __global__ void k_make_move(uint64_t* __restrict__ s, uint64_t* __restrict__ o, 
     }
 }
 
+template <int N>
 __global__ void k_status(const uint64_t* __restrict__ s, const uint64_t* __restrict__ o, int32_t* __restrict__ term,
                          int32_t* __restrict__ win, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        term[i] = is_terminal(s[i], o[i]);
+        term[i] = is_terminal_n<N>(s[i], o[i]);
         win[i] = winner(s[i], o[i]);
     }
 }
 
-// one wave per position: lane = square, three coalesced 256-B row stores per position
+// one wave per position: lane = square, three coalesced row stores per position (256 B on 8x8)
+template <int N>
 __global__ void k_tensor(const uint64_t* __restrict__ s, const uint64_t* __restrict__ o, float* __restrict__ out,
                          int64_t n) {
+    constexpr int CELLS = Geo<N>::CELLS;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t i = wave; i < n; i += nwaves) {
         const uint64_t sb = s[i], ob = o[i];
-        const uint64_t lg = legal_moves(sb, ob);
-        float* t = out + i * 192;
-        t[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;
-        t[64 + lane] = (ob >> lane) & 1ULL ? 1.0f : 0.0f;
-        t[128 + lane] = (lg >> lane) & 1ULL ? 1.0f : 0.0f;
+        const uint64_t lg = legal_moves_n<N>(sb, ob);
+        float* t = out + i * 3 * CELLS;
+        if (lane < CELLS) {
+            t[lane] = (sb >> lane) & 1ULL ? 1.0f : 0.0f;
+            t[CELLS + lane] = (ob >> lane) & 1ULL ? 1.0f : 0.0f;
+            t[2 * CELLS + lane] = (lg >> lane) & 1ULL ? 1.0f : 0.0f;
+        }
     }
 }
 
@@ -137,6 +144,7 @@ __host__ __device__ inline uint64_t lcg_skip(uint64_t x, uint64_t k) {
     return am * x + cm;
 }
 
+template <int N>
 __global__ void k_checksum(int64_t n, int64_t per_thread, Affine* legal_maps, Affine* flip_maps) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t lo = t * per_thread, hi = lo + per_thread < n ? lo + per_thread : n;
@@ -149,12 +157,12 @@ __global__ void k_checksum(int64_t n, int64_t per_thread, Affine* legal_maps, Af
             x = x * 6364136223846793005ULL + 1442695040888963407ULL; c = x;
             x = x * 6364136223846793005ULL + 1442695040888963407ULL; d = x;
             const uint64_t occ = (i & 1) ? (a | (c & d)) : (a & c);
-            const uint64_t sb = occ & d, ob = occ & ~d;
-            const uint64_t lb = legal_moves(sb, ob);
+            const uint64_t sb = occ & d & Geo<N>::all(), ob = occ & ~d & Geo<N>::all();
+            const uint64_t lb = legal_moves_n<N>(sb, ob);
             la = compose(la, Affine{0x100000001B3ULL, lb});
             if (lb) {
                 const int mv = __ffsll((unsigned long long)lb) - 1;
-                fa = compose(fa, Affine{0x100000001B3ULL, flip_bits(mv, sb, ob)});
+                fa = compose(fa, Affine{0x100000001B3ULL, flip_bits_n<N>(mv, sb, ob)});
             }
         }
     }
@@ -231,52 +239,64 @@ void oth_board_get_symmetries(const oth_board* b, const float* pi, float* states
 }
 
 // ---- section 2: batched device rules -----------------------------------------------------------
-int oth_legal_moves_batch(const uint64_t* s, const uint64_t* o, uint64_t* legal, int64_t n, void* stream) {
+#define OTH_BOARD_OK(bs, what) OTH_CHECK((bs) == 8 || (bs) == 6, what ": board_size must be 8 or 6")
+int oth_legal_moves_batch_n(int bs, const uint64_t* s, const uint64_t* o, uint64_t* legal, int64_t n, void* stream) {
     OTH_NEED_DEVICE();
+    OTH_BOARD_OK(bs, "oth_legal_moves_batch");
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && legal)), "oth_legal_moves_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
     OTH_BIND_PTR(s);
-    hipLaunchKernelGGL(k_legal, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, legal, n);
+    if (bs == 8) hipLaunchKernelGGL(k_legal<8>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, legal, n);
+    else hipLaunchKernelGGL(k_legal<6>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, legal, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
 }
-int oth_make_move_batch(uint64_t* s, uint64_t* o, const int32_t* pos, int32_t* ok, uint64_t* flips, int64_t n,
-                        void* stream) {
+int oth_make_move_batch_n(int bs, uint64_t* s, uint64_t* o, const int32_t* pos, int32_t* ok, uint64_t* flips, int64_t n,
+                          void* stream) {
     OTH_NEED_DEVICE();
+    OTH_BOARD_OK(bs, "oth_make_move_batch");
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && pos && ok)), "oth_make_move_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
     OTH_BIND_PTR(s);
-    hipLaunchKernelGGL(k_make_move, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, pos, ok, flips, n);
+    if (bs == 8) hipLaunchKernelGGL(k_make_move<8>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, pos, ok, flips, n);
+    else hipLaunchKernelGGL(k_make_move<6>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, pos, ok, flips, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
 }
-int oth_status_batch(const uint64_t* s, const uint64_t* o, int32_t* term, int32_t* win, int64_t n, void* stream) {
+int oth_status_batch_n(int bs, const uint64_t* s, const uint64_t* o, int32_t* term, int32_t* win, int64_t n, void* stream) {
     OTH_NEED_DEVICE();
+    OTH_BOARD_OK(bs, "oth_status_batch");
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && term && win)), "oth_status_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
     OTH_BIND_PTR(s);
-    hipLaunchKernelGGL(k_status, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, term, win, n);
+    if (bs == 8) hipLaunchKernelGGL(k_status<8>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, term, win, n);
+    else hipLaunchKernelGGL(k_status<6>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), s, o, term, win, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
 }
-int oth_tensor_input_batch(const uint64_t* s, const uint64_t* o, float* out, int64_t n, void* stream) {
+int oth_tensor_input_batch_n(int bs, const uint64_t* s, const uint64_t* o, float* out, int64_t n, void* stream) {
     OTH_NEED_DEVICE();
+    OTH_BOARD_OK(bs, "oth_tensor_input_batch");
     OTH_CHECK(n >= 0 && (n == 0 || (s && o && out)), "oth_tensor_input_batch: null pointer or negative n");
     if (n == 0) return OTH_OK;
     OTH_BIND_PTR(s);
-    hipLaunchKernelGGL(k_tensor, dim3(grid_for((n + 3) / 4 * 256, 256)), dim3(256), 0, as_stream(stream), s, o, out, n);
+    const dim3 grid(grid_for((n + 3) / 4 * 256, 256));
+    if (bs == 8) hipLaunchKernelGGL(k_tensor<8>, grid, dim3(256), 0, as_stream(stream), s, o, out, n);
+    else hipLaunchKernelGGL(k_tensor<6>, grid, dim3(256), 0, as_stream(stream), s, o, out, n);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
 }
-int oth_rules_checksum(int64_t n, uint64_t* legal_acc, uint64_t* flip_acc, void* stream) {
+int oth_rules_checksum_n(int bs, int64_t n, uint64_t* legal_acc, uint64_t* flip_acc, void* stream) {
     OTH_NEED_DEVICE();
+    OTH_BOARD_OK(bs, "oth_rules_checksum");
     OTH_CHECK(n >= 0 && legal_acc && flip_acc, "oth_rules_checksum: bad arguments");
     const int threads = 256 * 1024;
     const int64_t per = (n + threads - 1) / threads > 0 ? (n + threads - 1) / threads : 1;
     Affine *dl = nullptr, *df = nullptr;
     OTH_HIP(hipMalloc(&dl, sizeof(Affine) * threads));
     OTH_HIP(hipMalloc(&df, sizeof(Affine) * threads));
-    hipLaunchKernelGGL(k_checksum, dim3(threads / 256), dim3(256), 0, as_stream(stream), n, per, dl, df);
+    if (bs == 8) hipLaunchKernelGGL(k_checksum<8>, dim3(threads / 256), dim3(256), 0, as_stream(stream), n, per, dl, df);
+    else hipLaunchKernelGGL(k_checksum<6>, dim3(threads / 256), dim3(256), 0, as_stream(stream), n, per, dl, df);
     Affine* hl = new Affine[threads];
     Affine* hf = new Affine[threads];
     hipError_t e1 = hipMemcpyAsync(hl, dl, sizeof(Affine) * threads, hipMemcpyDeviceToHost, as_stream(stream));
@@ -297,6 +317,44 @@ int oth_rules_checksum(int64_t n, uint64_t* legal_acc, uint64_t* flip_acc, void*
     *legal_acc = la;
     *flip_acc = fa;
     return OTH_OK;
+}
+// the reference's board (8x8): the original entry points
+int oth_legal_moves_batch(const uint64_t* s, const uint64_t* o, uint64_t* legal, int64_t n, void* stream) {
+    return oth_legal_moves_batch_n(8, s, o, legal, n, stream);
+}
+int oth_make_move_batch(uint64_t* s, uint64_t* o, const int32_t* pos, int32_t* ok, uint64_t* flips, int64_t n,
+                        void* stream) {
+    return oth_make_move_batch_n(8, s, o, pos, ok, flips, n, stream);
+}
+int oth_status_batch(const uint64_t* s, const uint64_t* o, int32_t* term, int32_t* win, int64_t n, void* stream) {
+    return oth_status_batch_n(8, s, o, term, win, n, stream);
+}
+int oth_tensor_input_batch(const uint64_t* s, const uint64_t* o, float* out, int64_t n, void* stream) {
+    return oth_tensor_input_batch_n(8, s, o, out, n, stream);
+}
+int oth_rules_checksum(int64_t n, uint64_t* legal_acc, uint64_t* flip_acc, void* stream) {
+    return oth_rules_checksum_n(8, n, legal_acc, flip_acc, stream);
+}
+
+// ---- 6x6 host functions (single board): same header, N = 6 ------------------------------------------------------
+void oth_board_reset_n(int bs, oth_board* b) {
+    Board t;
+    if (bs == 6) reset_n<6>(t); else reset_n<8>(t);
+    b->self_board = t.self_b; b->opp_board = t.opp_b; b->move_count = 0; b->passed = 0;
+}
+uint64_t oth_legal_moves_n(int bs, uint64_t s, uint64_t o) { return bs == 6 ? legal_moves_n<6>(s, o) : legal_moves_n<8>(s, o); }
+uint64_t oth_flip_bits_n(int bs, int pos, uint64_t s, uint64_t o) {
+    if (pos < 0 || pos >= bs * bs) return 0;
+    return bs == 6 ? flip_bits_n<6>(pos, s, o) : flip_bits_n<8>(pos, s, o);
+}
+int oth_board_make_move_n(int bs, oth_board* b, int pos) {
+    Board t{b->self_board, b->opp_board, b->move_count, b->passed};
+    const int r = bs == 6 ? make_move_n<6>(t, pos) : make_move_n<8>(t, pos);
+    b->self_board = t.self_b; b->opp_board = t.opp_b; b->move_count = t.move_count; b->passed = t.passed;
+    return r;
+}
+int oth_board_is_terminal_n(int bs, const oth_board* b) {
+    return bs == 6 ? is_terminal_n<6>(b->self_board, b->opp_board) : is_terminal_n<8>(b->self_board, b->opp_board);
 }
 
 }  // extern "C"

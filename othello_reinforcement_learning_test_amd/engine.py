@@ -105,13 +105,18 @@ class SearchEngine:
 
     def __init__(self, max_games, num_simulations, temperature_threshold=15, c_puct=1.0,
                  dirichlet_alpha=0.3, dirichlet_epsilon=0.25, store_late_onehot=False, evaluator=None,
-                 eval_cache_log2=0):
+                 eval_cache_log2=0, board_size=None):
         _lib.require_device()
         self.max_games = int(max_games)
         self.num_simulations = int(num_simulations)
+        if board_size is None:   # follow the evaluator's network; 8 (the reference's game) otherwise
+            board_size = getattr(evaluator, "board_size", 8) if evaluator is not None else 8
+        self.board_size = int(board_size)
+        self.cells = self.board_size * self.board_size
+        self.npol = self.cells + 1
         cfg = _lib.EngineCfg(self.max_games, self.num_simulations, int(temperature_threshold),
                              float(c_puct), float(dirichlet_alpha), float(dirichlet_epsilon),
-                             1 if store_late_onehot else 0, int(eval_cache_log2))
+                             1 if store_late_onehot else 0, int(eval_cache_log2), self.board_size)
         self._h = _lib.load().oth_engine_create(C.byref(cfg))
         if not self._h:
             raise _lib.OthelloHipError("oth_engine_create: " + _lib.last_error())
@@ -155,10 +160,10 @@ class SearchEngine:
 
     def search_results(self, temperature=1.0):
         n = self._n
-        pi = np.zeros((n, 65), dtype=np.float32)
-        visits = np.zeros((n, 65), dtype=np.int32)
-        wsum = np.zeros((n, 65), dtype=np.float64)
-        prior = np.zeros((n, 65), dtype=np.float32)
+        pi = np.zeros((n, self.npol), dtype=np.float32)
+        visits = np.zeros((n, self.npol), dtype=np.int32)
+        wsum = np.zeros((n, self.npol), dtype=np.float64)
+        prior = np.zeros((n, self.npol), dtype=np.float32)
         _lib.call("oth_search_results", self._h, float(temperature), _lib.np_ptr(pi, C.c_float),
                   _lib.np_ptr(visits, C.c_int32), _lib.np_ptr(wsum, C.c_double),
                   _lib.np_ptr(prior, C.c_float), _lib.current_stream())
@@ -177,7 +182,7 @@ class SearchEngine:
             if len(s):
                 p, v = eval_fn(s, o, lg)
             else:
-                p, v = np.zeros((1, 65), np.float32), np.zeros(1, np.float32)
+                p, v = np.zeros((1, self.npol), np.float32), np.zeros(1, np.float32)
             self.search_expand(p, v, is_log=False)
         return self.search_results(temperature)
 
@@ -216,7 +221,7 @@ class SearchEngine:
         _lib.call("oth_selfplay_begin", self._h, self._n, _lib.current_stream())
 
     def selfplay_search(self):
-        pi = np.zeros((self._n, 65), dtype=np.float32)
+        pi = np.zeros((self._n, self.npol), dtype=np.float32)
         active = np.zeros(self._n, dtype=np.int32)
         _lib.call("oth_selfplay_search", self._h, _lib.np_ptr(pi, C.c_float),
                   _lib.np_ptr(active, C.c_int32), _lib.current_stream())
@@ -235,9 +240,9 @@ class SearchEngine:
         return n.value
 
     def selfplay_fetch(self, n_samples):
-        """-> host numpy arrays (states (n,3,8,8), pis (n,65), zs (n,), game_len (games,))"""
-        st = np.empty((n_samples, 3, 8, 8), dtype=np.float32)
-        pi = np.empty((n_samples, 65), dtype=np.float32)
+        """-> host numpy arrays (states (n,3,S,S), pis (n,S*S+1), zs (n,), game_len (games,))"""
+        st = np.empty((n_samples, 3, self.board_size, self.board_size), dtype=np.float32)
+        pi = np.empty((n_samples, self.npol), dtype=np.float32)
         z = np.empty((n_samples,), dtype=np.float32)
         gl = np.zeros((self._run_games,), dtype=np.int32)
         _lib.call("oth_selfplay_fetch", self._h, st.ctypes.data, pi.ctypes.data, z.ctypes.data,
@@ -259,7 +264,7 @@ class SearchEngine:
             iface = {"shape": (numel,), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
             holder = type("_DevMem", (), {"__cuda_array_interface__": iface})()
             return torch.as_tensor(holder, device="cuda").view(*shape)
-        return view(ps, (n, 3, 8, 8)), view(pp, (n, 65)), view(pz, (n,))
+        return view(ps, (n, 3, self.board_size, self.board_size)), view(pp, (n, self.npol)), view(pz, (n,))
 
     def counters(self):
         out = (C.c_int64 * 8)()

@@ -10,13 +10,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-_SO = os.path.join(ORACLE_DIR, "libothello_oracle.so")
+# Board size of THIS binding: 8 = the reference's game (libothello_oracle.so, pinned by the goldens).  The module
+# oracle_lib6 re-executes this file with _BOARD_OVERRIDE = 6 and binds libothello_oracle6.so (the same C file built
+# with -DORC_N=6: parity unpinned, checker of the engine's 6x6 path only).
+BOARD = globals().get("_BOARD_OVERRIDE", 8)
+CELLS = BOARD * BOARD
+NPOL = CELLS + 1
+_SO_NAME = "libothello_oracle.so" if BOARD == 8 else "libothello_oracle%d.so" % BOARD
+_SO = os.path.join(ORACLE_DIR, _SO_NAME)
 
 
 def build():
     src = os.path.join(ORACLE_DIR, "othello_oracle.c")
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libothello_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, _SO_NAME])
     return _SO
 
 
@@ -93,6 +100,10 @@ def lib():
         L.orc_selfplay_philox.restype = C.c_int64
         L.orc_selfplay_philox.argtypes = [C.POINTER(SelfplayCfg), C.c_int, C.c_uint64, C.c_int, EVAL_FN, C.c_void_p,
                                           C.c_int64, f32p, f32p, f32p, i32p, i32p]
+        assert L.orc_board_size() == BOARD
+        if BOARD != 8:   # the CPU network and the CPU-baseline drivers exist in the 8x8 build only
+            _lib = L
+            return _lib
         L.orc_net_blob_floats.restype = C.c_int64
         L.orc_net_blob_floats.argtypes = [C.c_int, C.c_int]
         L.orc_net_create.restype = C.c_void_p
@@ -150,21 +161,21 @@ def board(s=None, o=None, move_count=0, passed=0):
 
 
 def tensor(b):
-    t = np.empty(192, dtype=np.float32)
+    t = np.empty(3 * CELLS, dtype=np.float32)
     lib().orc_tensor(C.byref(b), _p(t, C.c_float))
-    return t.reshape(3, 8, 8)
+    return t.reshape(3, BOARD, BOARD)
 
 
 def legal_list(b):
-    out = np.empty(65, dtype=np.int32)
+    out = np.empty(NPOL, dtype=np.int32)
     n = lib().orc_legal_list(C.byref(b), _p(out, C.c_int32))
     return out[:n].tolist()
 
 
 def symmetries(b, pi):
     pi = np.ascontiguousarray(pi, dtype=np.float32)
-    st = np.empty((8, 3, 8, 8), dtype=np.float32)
-    ps = np.empty((8, 65), dtype=np.float32)
+    st = np.empty((8, 3, BOARD, BOARD), dtype=np.float32)
+    ps = np.empty((8, NPOL), dtype=np.float32)
     lib().orc_symmetries(C.byref(b), _p(pi, C.c_float), _p(st, C.c_float), _p(ps, C.c_float))
     return st, ps
 
@@ -177,7 +188,7 @@ def make_eval(py_fn):
         s = np.ctypeslib.as_array(sp, shape=(n,)).copy()
         o = np.ctypeslib.as_array(op, shape=(n,)).copy()
         p, v = py_fn(s, o)
-        np.ctypeslib.as_array(probs, shape=(n * 65,))[:] = np.asarray(p, dtype=np.float32).reshape(-1)
+        np.ctypeslib.as_array(probs, shape=(n * NPOL,))[:] = np.asarray(p, dtype=np.float32).reshape(-1)
         np.ctypeslib.as_array(values, shape=(n,))[:] = np.asarray(v, dtype=np.float32).reshape(-1)
     return EVAL_FN(_cb)
 
@@ -190,18 +201,18 @@ def numpy_rng():
         np.ctypeslib.as_array(out, shape=(n,))[:] = noise
 
     def _choice(ctx, pi):
-        p = np.ctypeslib.as_array(pi, shape=(65,)).copy()
-        return int(np.random.choice(65, p=p))
+        p = np.ctypeslib.as_array(pi, shape=(NPOL,)).copy()
+        return int(np.random.choice(NPOL, p=p))
     r = Rng(DIR_FN(_dir), CHOICE_FN(_choice), None)
     return r
 
 
 def search(b, sims, c_puct=1.0, temperature=1.0, eval_cb=None, add_noise=False, rng=None):
     cfg = SearchCfg(sims, c_puct, 0.3, 0.25, temperature, int(add_noise))
-    pi = np.zeros(65, dtype=np.float32)
-    visits = np.zeros(65, dtype=np.int32)
-    wsum = np.zeros(65, dtype=np.float64)
-    prior = np.zeros(65, dtype=np.float64)
+    pi = np.zeros(NPOL, dtype=np.float32)
+    visits = np.zeros(NPOL, dtype=np.int32)
+    wsum = np.zeros(NPOL, dtype=np.float64)
+    prior = np.zeros(NPOL, dtype=np.float64)
     lib().orc_search(C.byref(b), C.byref(cfg), eval_cb, None, C.byref(rng) if rng else None,
                      _p(pi, C.c_float), _p(visits, C.c_int32), _p(wsum, C.c_double),
                      _p(prior, C.c_double))
@@ -212,8 +223,8 @@ def search_batch(boards, sims, c_puct=1.0, temperature=1.0, eval_cb=None, add_no
     n = len(boards)
     arr = (Board * n)(*boards)
     cfg = SearchCfg(sims, c_puct, 0.3, 0.25, temperature, int(add_noise))
-    pi = np.zeros((n, 65), dtype=np.float32)
-    visits = np.zeros((n, 65), dtype=np.int32)
+    pi = np.zeros((n, NPOL), dtype=np.float32)
+    visits = np.zeros((n, NPOL), dtype=np.int32)
     lib().orc_search_batch(arr, n, C.byref(cfg), eval_cb, None, C.byref(rng) if rng else None,
                            _p(pi, C.c_float), _p(visits, C.c_int32))
     return pi, visits
@@ -223,8 +234,8 @@ def selfplay(kind, num_episodes, sims, threshold, eval_cb, rng=None, parallel_ga
              add_noise=True, max_plies=0, eval_ctx=None):
     cfg = SelfplayCfg(sims, threshold, parallel_games, c_puct, 0.3, 0.25, int(add_noise), max_plies)
     cap = num_episodes * 130
-    st = np.zeros((cap, 3, 8, 8), dtype=np.float32)
-    pi = np.zeros((cap, 65), dtype=np.float32)
+    st = np.zeros((cap, 3, BOARD, BOARD), dtype=np.float32)
+    pi = np.zeros((cap, NPOL), dtype=np.float32)
     z = np.zeros(cap, dtype=np.float32)
     mv = np.zeros(cap, dtype=np.int32)
     fn = lib().orc_selfplay_serial if kind == "serial" else lib().orc_selfplay_parallel
@@ -256,8 +267,8 @@ def selfplay_philox(num_games, seed, sims, threshold, eval_cb, parallel_games=64
     """The engine's device-RNG self-play restated on the CPU: -> states, pis, zs, moves, game_len."""
     cfg = SelfplayCfg(sims, threshold, parallel_games, c_puct, 0.3, 0.25, 0, 0)
     cap = num_games * 130
-    st = np.zeros((cap, 3, 8, 8), dtype=np.float32)
-    pi = np.zeros((cap, 65), dtype=np.float32)
+    st = np.zeros((cap, 3, BOARD, BOARD), dtype=np.float32)
+    pi = np.zeros((cap, NPOL), dtype=np.float32)
     z = np.zeros(cap, dtype=np.float32)
     mv = np.zeros(cap, dtype=np.int32)
     gl = np.zeros(num_games, dtype=np.int32)

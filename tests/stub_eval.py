@@ -38,13 +38,13 @@ def planes_to_bits(x):
     return s.astype(U64), o.astype(U64)
 
 
-def stub_index_value(self_b, opp_b):
-    """-> (idx int[N,65] in 0..15, value f32[N])."""
+def stub_index_value(self_b, opp_b, npol=65):
+    """-> (idx int[N,npol] in 0..15, value f32[N]).  npol = 65 (8x8) or 37 (6x6)."""
     with np.errstate(over="ignore"):
         s = np.asarray(self_b, dtype=U64).reshape(-1)
         o = np.asarray(opp_b, dtype=U64).reshape(-1)
         h = _mix(s ^ _mix(o + _G))
-        a = np.arange(65, dtype=U64)[None, :]
+        a = np.arange(npol, dtype=U64)[None, :]
         idx = ((_mix(h[:, None] + a * _A) >> U64(33)) & U64(15)).astype(np.int64)
         v = (((h >> U64(40)) & U64(0xFF)).astype(np.int64) - 128).astype(np.float32) / np.float32(128)
     return idx, v
@@ -60,7 +60,7 @@ def stub_logits_values(x, return_index=False):
     return logits, v
 
 
-def stub_probs_values(self_b, opp_b, exp_table):
-    """(self, opp) -> (probs f32[N,65] = exp_table[idx], values f32[N]) as the reference saw them."""
-    idx, v = stub_index_value(self_b, opp_b)
+def stub_probs_values(self_b, opp_b, exp_table, npol=65):
+    """(self, opp) -> (probs f32[N,npol] = exp_table[idx], values f32[N]) as the reference saw them."""
+    idx, v = stub_index_value(self_b, opp_b, npol)
     return np.asarray(exp_table, dtype=np.float32)[idx], v

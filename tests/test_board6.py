@@ -1,0 +1,233 @@
+"""6x6 board (BASELINE.json configs[4]; reference configs/debug_6x6.yaml): the alt board-size kernel path.
+
+PARITY UNPINNED for the rules and the search: the reference implements no 6x6 game (its `game.size` is never read),
+so there is no reference output to be exact with.  What IS checked, bit for bit: the HIP rules / search / self-play
+on 6x6 against the 6x6 build of the CPU oracle (oracle/libothello_oracle6.so -- the same C restatement compiled with
+-DORC_N=6; its 8x8 build is the one pinned by the reference-generated goldens), i.e. two independent
+implementations of one definition (include/othello_mi355x.h, "board size 6").  The 6x6 NETWORK is pinned against
+the reference's own outputs (tests/golden/g7_net6.npz; test_gpu_parity.py::test_net6_forward_vs_reference_outputs).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib6 as o6
+from stub_eval import stub_probs_values
+
+U64 = np.uint64
+ALL36 = (1 << 36) - 1
+
+
+def _lib():
+    from othello_reinforcement_learning_test_amd import _lib as L
+    return L
+
+
+def random_positions6(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a, c, d = (rng.integers(0, 2**36, n, dtype=np.int64).astype(U64) for _ in range(3))
+    occ = np.where(np.arange(n) % 2 == 0, a & c, a | (c & d))
+    return occ & d, occ & ~d
+
+
+# ------------------------------------------------------------------------------------------ host rules (CPU)
+def test_oracle6_is_the_documented_definition():
+    """bit i = row*6+col; start = the reference's centre pattern; the swapped-mask quirk is carried (L2)."""
+    b = o6.board()
+    assert b.self_board == (1 << 15) | (1 << 20) and b.opp_board == (1 << 14) | (1 << 21)
+    assert o6.legal_list(b) == [8, 13, 22, 27]
+    L = o6.lib()
+    # 8x8 probe of SURVEY L2, transplanted: self=A1, opp=B1 => C1 NOT legal (the +1 ray dies landing in... no: it
+    # passes B1, lands on C1: legal in real Othello; the reference's quirk makes the -1 ray from C1 die only in file A)
+    # self=B2 (7), opp=A2 (6) => the -1 ray from H1 (5)?  it wraps: 5+1=6 is A2 -> H1 legal, as on 8x8 (H1 legal there)
+    assert (L.orc_legal(1 << 7, 1 << 6) >> 5) & 1 == 1
+    # a +-6 ray is plain: self=(0,2), opp=(1,2) => (2,2) legal
+    assert (L.orc_legal(1 << 2, 1 << 8) >> 14) & 1 == 1
+    # nothing outside the 36 cells is ever legal
+    s, o = random_positions6(2000, 1)
+    assert not np.any(o6.legal_batch(s, o) & ~U64(ALL36))
+
+
+def test_host_rules_6x6_vs_oracle6():
+    L = _lib().load()
+    s, o = random_positions6(20000, 2)
+    want = o6.legal_batch(s, o)
+    got = np.array([L.oth_legal_moves_n(6, int(a), int(b)) for a, b in zip(s[:4000], o[:4000])], dtype=U64)
+    assert np.array_equal(got, want[:4000])
+    rng = np.random.Generator(np.random.PCG64(3))
+    pos = rng.integers(0, 36, len(s)).astype(np.int32)
+    wf = o6.flip_batch(s, o, pos)
+    gf = np.array([L.oth_flip_bits_n(6, int(p), int(a), int(b)) for p, a, b in zip(pos[:4000], s[:4000], o[:4000])], dtype=U64)
+    assert np.array_equal(gf, wf[:4000])
+    # whole random games, move by move (make_move incl. passes and invalid moves, is_terminal)
+    B = _lib().Board
+    for g in range(60):
+        hb, ob = B(), o6.board()
+        L.oth_board_reset_n(6, C.byref(hb))
+        assert (hb.self_board, hb.opp_board) == (ob.self_board, ob.opp_board)
+        while True:
+            term = o6.lib().orc_is_terminal(ob)
+            assert L.oth_board_is_terminal_n(6, C.byref(hb)) == term
+            if term:
+                break
+            mv = o6.legal_list(ob)
+            bad = int(rng.integers(-1, 38))
+            if bad not in mv:     # an invalid move leaves the state untouched (pyx:219-236)
+                assert L.oth_board_make_move_n(6, C.byref(hb), bad) == 0
+                assert (hb.self_board, hb.opp_board, hb.move_count) == (ob.self_board, ob.opp_board, ob.move_count)
+            a = int(mv[rng.integers(len(mv))])
+            assert L.oth_board_make_move_n(6, C.byref(hb), a) == 1 and o6.lib().orc_make_move(ob, a) == 1
+            assert (hb.self_board, hb.opp_board, hb.move_count, hb.passed) == \
+                   (ob.self_board, ob.opp_board, ob.move_count, ob.passed)
+    # the 8x8 forms of the _n functions are the reference's functions
+    import oracle_lib as o8
+    s8 = rng.integers(0, 2**63, 500, dtype=np.int64).astype(U64)
+    o8b = rng.integers(0, 2**63, 500, dtype=np.int64).astype(U64) & ~s8
+    assert np.array_equal(np.array([L.oth_legal_moves_n(8, int(a), int(b)) for a, b in zip(s8, o8b)], dtype=U64),
+                          o8.legal_batch(s8, o8b))
+
+
+# ------------------------------------------------------------------------------------------ device (GPU)
+@pytest.fixture(scope="module")
+def pkg():
+    import othello_reinforcement_learning_test_amd as p
+    p._lib.require_device()
+    return p
+
+
+def dev_u64(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=U64).view(np.int64)).cuda()
+
+
+@pytest.mark.gpu
+def test_device_rules_6x6_vs_oracle6(pkg):
+    import torch
+    s, o = random_positions6(200_000, 5)
+    ds, do = dev_u64(s), dev_u64(o)
+    lg = torch.empty_like(ds)
+    pkg._lib.call("oth_legal_moves_batch_n", 6, ds.data_ptr(), do.data_ptr(), lg.data_ptr(), len(s), None)
+    assert np.array_equal(lg.cpu().numpy().view(U64), o6.legal_batch(s, o))
+    term = torch.empty(len(s), dtype=torch.int32, device="cuda")
+    win = torch.empty(len(s), dtype=torch.int32, device="cuda")
+    pkg._lib.call("oth_status_batch_n", 6, ds.data_ptr(), do.data_ptr(), term.data_ptr(), win.data_ptr(), len(s), None)
+    for i in range(0, 20000, 53):
+        b = o6.board(s[i], o[i])
+        assert term[i].item() == o6.lib().orc_is_terminal(b) and win[i].item() == o6.lib().orc_winner(b)
+    # make_move incl. invalid moves
+    rng = np.random.Generator(np.random.PCG64(8))
+    mv = rng.integers(-2, 39, len(s)).astype(np.int32)
+    dm = torch.from_numpy(mv).cuda()
+    ok = torch.empty(len(s), dtype=torch.int32, device="cuda")
+    fl = torch.empty_like(ds)
+    pkg._lib.call("oth_make_move_batch_n", 6, ds.data_ptr(), do.data_ptr(), dm.data_ptr(), ok.data_ptr(), fl.data_ptr(),
+                  len(s), None)
+    hs, ho, hok = ds.cpu().numpy().view(U64), do.cpu().numpy().view(U64), ok.cpu().numpy()
+    for i in range(0, len(s), 41):
+        b = o6.board(s[i], o[i])
+        r = o6.lib().orc_make_move(b, int(mv[i]))
+        assert r == hok[i] and (b.self_board, b.opp_board) == (int(hs[i]), int(ho[i]))
+    # tensor planes [n,3,6,6]
+    s2, o2 = random_positions6(300, 6)
+    t = torch.empty((300, 3, 6, 6), dtype=torch.float32, device="cuda")
+    ds2, do2 = dev_u64(s2), dev_u64(o2)   # keep the tensors alive across the call
+    pkg._lib.call("oth_tensor_input_batch_n", 6, ds2.data_ptr(), do2.data_ptr(), t.data_ptr(), 300, None)
+    torch.cuda.synchronize()
+    want = np.stack([o6.tensor(o6.board(a, b)) for a, b in zip(s2, o2)])
+    assert np.array_equal(t.cpu().numpy(), want)
+    # size-independent property: checksum over an LCG position stream, 2 M positions
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    pkg._lib.call("oth_rules_checksum_n", 6, 2_000_000, C.byref(a), C.byref(b), None)
+    assert (a.value, b.value) == o6.rules_checksum(2_000_000)
+
+
+def game_positions6(n_games, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for _ in range(n_games):
+        b = o6.board()
+        while not o6.lib().orc_is_terminal(b):
+            out.append((b.self_board, b.opp_board, b.move_count))
+            mv = o6.legal_list(b)
+            o6.lib().orc_make_move(b, int(mv[rng.integers(len(mv))]))
+    return out
+
+
+@pytest.mark.gpu
+def test_search_6x6_vs_oracle6(pkg, golden):
+    """PUCT search on 6x6 under the closed-form stub evaluator: visits, float64 value sums, float32 priors (numpy's
+    pairwise sum over 37 entries: 4 groups of 8 + 5 trailing elements) and pi equal the 6x6 oracle's."""
+    table = golden("g3_search.npz")["stub_exp"]
+    ev = o6.make_eval(lambda s, o: stub_probs_values(s, o, table, 37))
+    pos = game_positions6(12, 9)
+    late = [p for p in pos if p[2] >= 26][:48]
+    pick = pos[:120:2] + late
+    for sims, cp in ((25, 1.0), (100, 1.5)):
+        eng = pkg.SearchEngine(len(pick), sims, c_puct=cp, board_size=6)
+        pi, visits, wsum, prior = eng.search_with([p[0] for p in pick], [p[1] for p in pick],
+                                                  lambda s, o, lg: stub_probs_values(s, o, table, 37))
+        assert pi.shape == (len(pick), 37)
+        assert eng.counters()["terminal_sims"] > 0
+        for i, (s, o, _) in enumerate(pick):
+            opi, on, ow, opr = o6.search(o6.board(s, o), sims, cp, 1.0, ev)
+            assert np.array_equal(visits[i], on), (sims, i)
+            assert np.array_equal(wsum[i], ow) and np.array_equal(pi[i], opi)
+            assert np.array_equal(prior[i], opr.astype(np.float32))
+
+
+def hip_net_eval6(ev, cap):
+    import torch  # noqa: F401
+
+    def fn(s, o):
+        n = len(s)
+        probs = np.empty((n, 37), dtype=np.float32)
+        vals = np.empty(n, dtype=np.float32)
+        for i in range(0, n, cap):
+            m = min(cap, n - i)
+            ss, oo = np.zeros(cap, dtype=U64), np.zeros(cap, dtype=U64)
+            ss[:m], oo[:m] = s[i:i + m], o[i:i + m]
+            lg = o6.legal_batch(ss, oo)
+            logp, v = ev.forward_bits(dev_u64(ss), dev_u64(oo), dev_u64(lg))
+            probs[i:i + m] = ev.policy_probs(logp)[:m].cpu().numpy()
+            vals[i:i + m] = v[:m, 0].cpu().numpy()
+        return probs, vals
+    return o6.make_eval(fn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,nf,sims,slots,games", [(5, 64, 25, 32, 80), (2, 16, 10, 16, 40)])
+def test_selfplay_6x6_exact_vs_oracle6(pkg, nb, nf, sims, slots, games):
+    """configs[4] shape (5x64 network on 6x6, 25 sims/move): the engine's whole (state, pi, z) stream, game lengths
+    and counters equal the 6x6 oracle driven by the HIP network's own outputs; streaming mode included."""
+    import torch
+    torch.manual_seed(60 + nf)
+    net = pkg.OthelloResNet(nb, nf, board_size=6).eval()
+    ev = pkg.HipResNetEvaluator(net)
+    eng = pkg.SearchEngine(slots, sims, temperature_threshold=8, evaluator=ev)
+    assert eng.board_size == 6
+    seed = 4242
+    n = eng.selfplay_run(games, seed)
+    st, pi, z, gl = eng.selfplay_fetch(n)
+    assert st.shape == (n, 3, 6, 6) and pi.shape == (n, 37) and gl.max() <= 40
+    cb = hip_net_eval6(ev, slots)
+    ws, wp, wz, wm, wl = o6.selfplay_philox(games, seed, sims, 8, cb, parallel_games=slots)
+    assert np.array_equal(gl, wl)
+    assert np.array_equal(st, ws) and np.array_equal(pi, wp) and np.array_equal(z, wz)
+    # streaming: every harvested game is the oracle's game of that id
+    eng.stream_begin(seed, stagger_rounds=5, hist_games=4 * slots)
+    woff = np.concatenate([[0], np.cumsum(wl)])
+    for _ in range(2):
+        g, m = eng.stream_step(slots // 2)
+        st, pi, z, gl = eng.selfplay_fetch(m)
+        off = 0
+        for gid, ln in zip(eng.game_ids(), gl):
+            if gid < games:
+                a, b = woff[gid], woff[gid + 1]
+                assert ln == wl[gid] and np.array_equal(st[off:off + ln], ws[a:b]) and np.array_equal(pi[off:off + ln], wp[a:b])
+                assert np.array_equal(z[off:off + ln], wz[a:b])
+            off += ln
+    # a network of the wrong board size is refused, loudly
+    net8 = pkg.OthelloResNet(2, 16).eval()
+    with pytest.raises(pkg._lib.OthelloHipError):
+        pkg.SearchEngine(4, 2, evaluator=pkg.HipResNetEvaluator(net8), board_size=6)
