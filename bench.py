@@ -38,17 +38,19 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL
 
 MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak, MI355X_MICROARCH.md
 PLIES_PER_GAME = 60.7           # measured by the engine over >100k games of this workload
 # Planning figure for the time budget only (tests/test_bench_budget.py): games/s one MI355X sustains on the default
 # workload, taken well below the slowest box measured (503-528 in round 1).
 PLANNING_RATE = 420.0
 
 
-def mflop_per_position(blocks, filters):
-    """Algorithmic MFLOP of one forward pass (2 x MACs): stem 3x3x3 -> F, 2*blocks 3x3 F -> F convs on 64 cells, the two
-    1x1 head convs and the three head FCs.  10x128: 189 014 400 MACs = 378.03 MFLOP."""
-    f = filters
-    macs = 64 * 27 * f + 2 * blocks * 64 * 9 * f * f + 64 * f * 2 + 64 * f + 128 * 65 + 64 * 256 + 256
+def mflop_per_position(blocks, filters, board=8):
+    """Algorithmic MFLOP of one forward pass (2 x MACs): stem 3x3x3 -> F, 2*blocks 3x3 F -> F convs on the board's
+    cells, the two 1x1 head convs and the three head FCs.  10x128 on 8x8: 189 014 400 MACs = 378.03 MFLOP
+    (SURVEY.md 8(d))."""
+    f, c = filters, board * board
+    macs = c * 27 * f + 2 * blocks * c * 9 * f * f + c * f * 2 + c * f + 2 * c * (c + 1) + c * 256 + 256
     return 2.0 * macs / 1e6
 
 
@@ -140,7 +142,10 @@ def main():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
-    ap.add_argument("--precision", default=None, help="f16x3 (default for 128 filters), f16, f32")
+    ap.add_argument("--precision", default=None, help="f16x3 (default for 128 filters on 8x8), f16, f32 (exact, MFMA)")
+    ap.add_argument("--board", type=int, default=8,
+                    help="8 (the reference's game) or 6 (BASELINE configs[4], e.g. --board 6 --blocks 5 --filters 64 "
+                         "--sims 25; rules parity UNPINNED: the reference has no 6x6 rules)")
     ap.add_argument("--lanes", type=int, default=2,
                     help="independent game groups per GPU, each --games/--lanes slots on its own stream and host "
                          "thread (their kernels overlap: tails and tree phases of one lane are filled by the other)")
@@ -174,7 +179,7 @@ def main():
             print("[bench %6.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
 
     torch.manual_seed(42)
-    net = pkg.OthelloResNet(args.blocks, args.filters).eval()
+    net = pkg.OthelloResNet(args.blocks, args.filters, board_size=args.board).eval()
     ev = pkg.HipResNetEvaluator(net, precision=args.precision)
     import threading
     lanes = max(1, args.lanes)
@@ -237,7 +242,12 @@ def main():
             raise errors[0]
         return out
 
-    all_lanes(lambda e, k: e.stream_begin(42 + 1000003 * (rank * lanes + k), stagger_rounds=args.stagger))
+    # history ring per lane: room for the largest step target (+10 % rebalancing, + the games finishing while the
+    # last rounds of a step are in flight) next to the games in flight
+    per_lane = args.games // lanes
+    hist = max(8 * per_lane, 2 * (int(1.1 * args.step_games) // lanes + 1) + 4 * per_lane)
+    all_lanes(lambda e, k: e.stream_begin(42 + 1000003 * (rank * lanes + k), stagger_rounds=args.stagger,
+                                          hist_games=hist))
 
     def step():
         """-> (games this rank finished, replay samples of the whole job after the exchange)"""
@@ -332,15 +342,16 @@ def main():
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
         # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
         net_s = prof["union_ms"] * 1e-3
-        flops = prof["evals"] * mflop_per_position(args.blocks, args.filters) * 1e6
+        flops = prof["evals"] * mflop_per_position(args.blocks, args.filters, args.board) * 1e6
         achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
         prec = ev.precision
         # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
         # source row is zero padding (1/12 of the conv work is skipped by the shipped kernel)
         issued = (3.0 if prec == "f16x3" else 1.0) * (11.0 / 12.0 if prec != "f32" else 1.0)
+        peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
         evals_per_game = stats["evals"] / max(1, stats["games"])
         out = {
-            "metric": "self-play games/sec (8x8, 50 MCTS sims/move)",
+            "metric": "self-play games/sec (%dx%d, %d MCTS sims/move)" % (args.board, args.board, args.sims),
             "value": round(total_games / dt, 3),
             "unit": "games/s",
             "n_gpus": world,
@@ -351,11 +362,14 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f16x3": "f16x3 (fp16 hi/lo operand split on MFMA, fp32 accumulate; fp32-equivalent)",
-                      "f16": "f16 (single fp16 MFMA pass, fp32 accumulate)", "f32": "f32"}[prec],
+                      "f16": "f16 (single fp16 MFMA pass, fp32 accumulate)",
+                      "f32": "f32 (exact fp32 on v_mfma_f32_16x16x4_f32)"}[prec],
             "data": "synthetic",
             "config": {
-                "workload": "8x8, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank"
-                            % (args.sims, args.blocks, args.filters, args.games),
+                "workload": "%dx%d, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank%s"
+                            % (args.board, args.board, args.sims, args.blocks, args.filters, args.games,
+                               "" if args.board == 8 else " -- 6x6 RULES PARITY UNPINNED (the reference implements no 6x6 "
+                               "game; checked against the 6x6 build of the CPU oracle only)"),
                 "step": "steady-state streaming: a step ends when >= %d more games per GPU have finished (slots stay "
                         "full across steps; staggered start over %d ply rounds during warm-up)" % (args.step_games, args.stagger),
                 "games_timed": total_games, "concurrent_games_per_gpu": args.games,
@@ -375,14 +389,15 @@ def main():
                 "timing_hooks_in_timed_region": False,
             },
             "roofline": {
-                "kernel": "k_trunk (fused ResNet forward)", "bound": "mfma",
-                "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                "kernel": "k_trunk (fused ResNet forward)" if prec != "f32" else "k_trunk_f32 (fused ResNet forward, fp32 MFMA)",
+                "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic if prec != "f32" else None,
                 "traffic_basis": "PMC FETCH_SIZE/WRITE_SIZE of a full launch of 4096 positions "
                                  "(profiles/%s); algorithmic bytes of that launch: 1.18 MB" % traffic_file,
                 "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"
                                % (args.profile_steps, prof["games"], prof["wall_s"]),
-                "frac_mfma_issue": round(achieved * issued / PEAK_F16_TFLOPS, 4),
+                "frac_mfma_issue": round(achieved * issued / peak, 4),
                 "launches": prof["net_launches"],
                 "avg_launch_ms": round(prof["net_ms"] / max(1, prof["net_launches"]), 4),
                 "busy_ms": round(prof["union_ms"], 1), "concurrent_lanes": lanes,
@@ -397,7 +412,7 @@ def main():
         }
         # evidence first: if the CPU leg were to be killed the measured line is already on stderr
         print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.board == 8:   # the oracle's CPU network is 8x8 only
             try:
                 out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget, evals_per_game)
             except Exception as exc:   # the GPU result must still be reported

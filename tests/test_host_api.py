@@ -174,3 +174,22 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert r.stdout.startswith("ok %d entry points" % len(names))
+
+
+def test_integration_md_cfg_struct_matches_the_header():
+    """The ctypes struct printed in INTEGRATION.md must have exactly the fields of oth_engine_cfg (a shorter struct
+    would make oth_engine_create read past the caller's memory)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"class Cfg\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n", md, flags=re.S)
+    doc_fields = re.findall(r'\("(\w+)", C\.(\w+)\)', m.group(1))
+    from othello_reinforcement_learning_test_amd import _lib
+    import ctypes as C
+    lib_fields = [(n, t) for n, t in _lib.EngineCfg._fields_]
+    assert [(n, getattr(C, t)) for n, t in doc_fields] == lib_fields
+    hdr = open(os.path.join(root, "include", "othello_mi355x.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} oth_engine_cfg;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    hdr_fields = re.findall(r"(?:int32_t|float|double)\s+(\w+);", body)
+    assert hdr_fields == [n for n, _ in lib_fields]
