@@ -217,7 +217,8 @@ int oth_selfplay_end(oth_engine *e, int64_t *n_samples, void *stream);
  *          late so the device never idles: the step ends with the round after the one that reached the target),
  *          then compact the tuples of ALL games finished so far, ascending game id.  Synchronous.  Read them with
  *          oth_selfplay_fetch / oth_selfplay_device_ptrs; oth_selfplay_game_ids gives their ids.
- * oth_engine_counters are cumulative over the stream. */
+ * oth_engine_counters are cumulative over the stream.  The network's weights may be reloaded between steps (games
+ * in flight then continue with the new weights; the optional evaluation cache is cleared at every step). */
 int oth_stream_begin(oth_engine *e, uint64_t seed, int32_t stagger_rounds, int32_t hist_games, void *stream);
 int oth_stream_step(oth_engine *e, int32_t min_games, int32_t *n_games /*HOST*/, int64_t *n_samples /*HOST*/,
                     void *stream);

@@ -1367,6 +1367,7 @@ int oth_stream_step(oth_engine* e, int32_t min_games, int32_t* n_games, int64_t*
     hipStream_t s = as_stream(stream);
     spans_reset(e);
     int r;
+    if ((r = cache_clear(e, s))) return r;  // a step is where a trainer would have changed the weights
     // Rounds are enqueued one ahead of the check (see oth_selfplay_run): the step ends with the round that was
     // already in flight when the round before it was seen to reach the target -- a deterministic rule.
     const int first = e->round + 1;
