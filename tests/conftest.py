@@ -32,10 +32,15 @@ def pytest_sessionstart(session):
         return
     out = tempfile.NamedTemporaryFile("w+", suffix=".json", delete=False)
     err = tempfile.NamedTemporaryFile("w+", suffix=".err", delete=False)
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     env = dict(os.environ)
     env.update({"OTHELLO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "64", "--step-games", "32", "--sims", "6",
            "--blocks", "2", "--filters", "16", "--stagger", "8", "--profile-steps", "1", "--no-cpu-baseline"]
     REHEARSAL["proc"] = subprocess.Popen(cmd, stdout=out, stderr=err, env=env, cwd=ROOT)
