@@ -74,7 +74,8 @@ class BatchMCTS:
 class ParallelSelfPlayWorker:
     def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
                  num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
-                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=None):
+                 rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=None, continuous=False,
+                 stagger_rounds=0):
         self.board_class = board_class
         self.num_simulations = num_simulations
         self.temperature_threshold = temperature_threshold
@@ -104,6 +105,16 @@ class ParallelSelfPlayWorker:
                                                dirichlet_epsilon=dirichlet_epsilon, store_late_onehot=False,
                                                evaluator=self.batch_mcts.evaluator, eval_cache_log2=eval_cache_log2)
                                   for _ in range(self.lanes)]
+        # continuous=True (device RNG only): the slots keep playing BETWEEN execute_episodes calls (oth_stream_*): a call
+        # returns the games that finished during it -- at least num_episodes -- and leaves the others in flight, so
+        # no call pays for a ragged tail.  Opt-in because a game can then span a weight update of the trainer, which
+        # the reference's call-by-call worker never does (parallel_self_play.py:300-316 starts every batch afresh).
+        self.continuous = bool(continuous)
+        self.stagger_rounds = int(stagger_rounds)
+        self._streaming = False
+        self.last_game_ids = None
+        if self.continuous and self.rng_mode != "device":
+            raise ValueError("continuous=True needs rng_mode='device'")
         self.last_stats = {}
         self._ran = [self.engine]   # engines the last device-RNG call ran on
 
@@ -142,6 +153,19 @@ class ParallelSelfPlayWorker:
         if errors:
             raise errors[0]
         return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
+
+    def _run_stream(self, num_episodes):
+        """continuous mode, single engine: -> arrays of every game that finished during this call (>= num_episodes)."""
+        eng = self.engine
+        self._ran = [eng]
+        if not self._streaming:
+            self.stream_seed = int(np.random.randint(0, 2**62))
+            eng.stream_begin(self.stream_seed, stagger_rounds=self.stagger_rounds,
+                             hist_games=max(8 * eng.max_games, 2 * int(num_episodes) + 4 * eng.max_games))
+            self._streaming = True
+        g, n = eng.stream_step(int(num_episodes))
+        self.last_game_ids = eng.game_ids()
+        return eng.selfplay_fetch(n)[:3]
 
     # ---- numpy RNG: the reference's lock-step batches, draws in the reference's order --------
     def _execute_batch_numpy(self, batch_size, add_dirichlet_noise):
@@ -183,7 +207,10 @@ class ParallelSelfPlayWorker:
         self.batch_mcts.evaluator.refresh()
         t0 = time.time()
         if self.rng_mode == "device":
-            states, pis, zs = self._run_device(num_episodes, add_dirichlet_noise)
+            if self.continuous:
+                states, pis, zs = self._run_stream(num_episodes)
+            else:
+                states, pis, zs = self._run_device(num_episodes, add_dirichlet_noise)
             data = tuples_from_arrays(states, pis, zs)
         else:
             data = []

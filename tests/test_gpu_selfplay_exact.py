@@ -283,3 +283,39 @@ def test_batch_mcts_search_batch_vs_reference(pkg, golden):
     res0 = bm.search_batch(boards[:5], 50, temperature=0.0)
     for (p0, _), (p1, _) in zip(res0, res[:5]):
         assert p0.sum() == 1.0 and p0[np.argmax(p1)] == 1.0
+
+
+def test_worker_continuous_mode_exact_with_cache_and_refresh(pkg):
+    """ParallelSelfPlayWorker(continuous=True): successive execute_episodes calls return the oracle's games by id
+    (>= the requested number each), with the evaluation cache on (bit-identical by construction) and an unchanged
+    model re-uploaded between the calls (evaluator.refresh(force=True) + the per-step cache clear)."""
+    torch.manual_seed(8)
+    net = pkg.OthelloResNet(2, 16).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=6, temperature_threshold=8,
+                                   num_parallel_games=16, verbose=False, continuous=True, stagger_rounds=4,
+                                   eval_cache_log2=12)
+    np.random.seed(5)
+    calls, ids = [], []
+    for want in (12, 5, 20):
+        data = w.execute_episodes(want)
+        ids.append(w.last_game_ids.copy())
+        calls.append(data)
+        assert len(ids[-1]) >= want
+        w.batch_mcts.evaluator.refresh(force=True)
+    all_ids = np.concatenate(ids)
+    assert len(set(all_ids.tolist())) == len(all_ids)
+    n_oracle = int(all_ids.max()) + 1
+    cb = hip_net_eval(w.batch_mcts.evaluator, 16)
+    ws, wp, wz, wm, wl = ol.selfplay_philox(n_oracle, w.stream_seed, 6, 8, cb, parallel_games=n_oracle)
+    woff = np.concatenate([[0], np.cumsum(wl)])
+    for data, gids in zip(calls, ids):
+        off = 0
+        for gid in gids:
+            a, b = woff[gid], woff[gid + 1]
+            chunk = data[off:off + (b - a)]
+            assert np.array_equal(np.stack([d[0] for d in chunk]), ws[a:b])
+            assert np.array_equal(np.stack([d[1] for d in chunk]), wp[a:b])
+            assert np.array_equal(np.array([d[2] for d in chunk], dtype=np.float32), wz[a:b])
+            off += b - a
+        assert off == len(data)
+    assert w.last_stats["cache_hits"] > 0
