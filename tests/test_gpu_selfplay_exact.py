@@ -69,6 +69,9 @@ CASES = [
     pytest.param(2, 32, 12, 4, 8, 20, False, id="2x32-12sims"),
     pytest.param(10, 128, 50, 15, 32, 64, False, id="10x128-50sims-64games-32slots"),
     pytest.param(10, 128, 20, 15, 512, 600, False, id="10x128-20sims-600games-512slots-pair-kernel"),
+    # BASELINE.json configs[1] at FULL size: 4096 concurrent games, 50 sims, 10x128 -- 248k tuples, 11.8 M network
+    # evaluations, every one of them compared (about 50 s: 9 s of device play, the rest is the oracle's replay)
+    pytest.param(10, 128, 50, 15, 4096, 4096, False, id="FULL-SIZE-10x128-50sims-4096games-4096slots"),
 ]
 
 
