@@ -32,8 +32,11 @@ class GameStep:  # self_play.py:17-22
 
 
 def tuples_from_arrays(states, pis, zs):
-    """Arrays -> the list of tuples of fresh numpy arrays the trainer/ReplayBuffer keep (buffer.py:45)."""
-    return [(states[i].copy(), pis[i].copy(), float(zs[i])) for i in range(len(zs))]
+    """Arrays -> the list of (state, pi, z) tuples the trainer/ReplayBuffer keep (buffer.py:45).  The arrays passed in
+    are freshly allocated by every fetch and never written again, so each tuple holds row VIEWS of them (what
+    iterating a numpy array yields) instead of 2 x 250 000 small copies per 4096 games; z is a Python float as in
+    the reference (self_play.py:127)."""
+    return list(zip(states, pis, zs.tolist()))
 
 
 class SelfPlayWorker:
