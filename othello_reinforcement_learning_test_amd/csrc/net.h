@@ -44,6 +44,7 @@ struct HeadParams {
 
 struct MfmaWeights;  // net_mfma.hip
 struct F32Weights;   // net_f32.hip
+struct H3Weights;    // net_h3.hip
 
 }  // namespace oth
 
@@ -58,6 +59,8 @@ struct oth_net {
     oth::F32Weights* f32 = nullptr;
     // fp16-split MFMA path (128 filters, 8x8): net_mfma.hip
     oth::MfmaWeights* mfma = nullptr;
+    // fp16-split MFMA path, one wave per position (32 / 64 filters, 8x8 and 6x6): net_h3.hip
+    oth::H3Weights* h3 = nullptr;
 };
 
 namespace oth {
@@ -65,6 +68,10 @@ int mfma_pack_weights(oth_net* net, int precision);  // net_mfma.hip
 void mfma_free_weights(oth_net* net);
 int mfma_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
                  const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
+int h3_pack_weights(oth_net* net);  // net_h3.hip
+void h3_free_weights(oth_net* net);
+int h3_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
+               const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 int f32_pack_weights(oth_net* net);  // net_f32.hip
 void f32_free_weights(oth_net* net);
 int f32_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,

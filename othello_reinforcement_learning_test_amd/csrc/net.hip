@@ -83,6 +83,7 @@ static void net_free_device(oth_net* net) {
     if (net->d_heads) (void)hipFree(net->d_heads);
     net->d_heads = nullptr;
     f32_free_weights(net);
+    h3_free_weights(net);
     mfma_free_weights(net);
 }
 
@@ -129,9 +130,13 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
               (long long)state_floats(net->blocks, net->filters, net->board));
     OTH_CHECK(precision == OTH_PREC_F32 || precision == OTH_PREC_F16X3 || precision == OTH_PREC_F16,
               "oth_net_load_state: unknown precision %d", precision);
-    if (precision != OTH_PREC_F32 && (net->filters != 128 || net->board != 8)) {
-        set_error("oth_net_load_state: the fp16-split MFMA kernel is built for 128 filters on 8x8; use OTH_PREC_F32 "
-                  "(exact fp32 MFMA) for %d filters / board %d", net->filters, net->board);
+    // fp16-split kernels: 128 filters on 8x8 (k_trunk16: f16x3 and the single-pass f16), 32 / 64 filters on either
+    // board (k_trunk_h3: f16x3 only); everything else runs the exact-fp32 MFMA kernel
+    const bool wide = net->filters == 128 && net->board == 8;
+    const bool narrow = net->filters == 32 || net->filters == 64;
+    if (precision != OTH_PREC_F32 && !(wide || (narrow && precision == OTH_PREC_F16X3))) {
+        set_error("oth_net_load_state: no fp16-split kernel for %d filters on a %dx%d board at precision %d; use "
+                  "OTH_PREC_F32 (exact fp32 MFMA)", net->filters, net->board, net->board, precision);
         return OTH_E_UNSUPPORTED;
     }
     parse_blob(net->host, net->blocks, net->filters, net->board, blob);
@@ -152,7 +157,8 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
     OTH_HIP(hipMemcpy(net->d_heads, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* d = net->d_heads;
     net->heads = HeadParams{d + o_pw, d + o_pb, d + o_vw, d + o_vb, d + o_pfw, d + o_pfb, d + o_v1w, d + o_v1b, d + o_v2w, d + o_v2b};
-    int r = precision == OTH_PREC_F32 ? f32_pack_weights(net) : mfma_pack_weights(net, precision);
+    int r = precision == OTH_PREC_F32 ? f32_pack_weights(net)
+                                      : (net->filters == 128 ? mfma_pack_weights(net, precision) : h3_pack_weights(net));
     if (r != OTH_OK) return r;
     net->precision = precision;
     return OTH_OK;
@@ -165,8 +171,9 @@ int oth_net_forward_bits(oth_net* net, const uint64_t* sb, const uint64_t* ob, c
     OTH_CHECK(n >= 0 && (n == 0 || (sb && ob && lg && logp && v)), "oth_net_forward: null pointer or negative n");
     if (n == 0) return OTH_OK;
     OTH_BIND(net->device);
-    if (net->precision != OTH_PREC_F32) return mfma_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
-    return f32_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
+    if (net->precision == OTH_PREC_F32) return f32_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
+    if (net->h3) return h3_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
+    return mfma_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
 }
 
 int oth_net_forward_planes(oth_net* net, const float* x, int64_t n, float* logp, float* v, void* stream) {

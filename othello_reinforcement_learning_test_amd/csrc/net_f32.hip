@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "net.h"
+#include "net_heads_wave.h"
 
 namespace oth {
 
@@ -54,17 +55,6 @@ struct F32Args {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-
 template <int F, int BS, int P>
 struct TrunkGeom {
     static constexpr int NB = F / 16;               // 16-channel row blocks
@@ -195,56 +185,11 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_f32(F32Args a, const uint64_
     }
 
     // ---- heads (net.py:62-136), one position at a time, whole wave
-    const HeadParams& hp = a.heads;
     for (int p = 0; p < P; ++p) {
         if (pos0 + p >= nv) break;
-        {   // 1x1 convs (+ folded BN) + ReLU: lane = cell
-            const int c = lane < CELLS ? lane : 0;
-            const float* src = act + p * POSW + (c / BS + 1) * PW + (c % BS + 1);
-            float a0 = 0.f, a1 = 0.f, av = 0.f;
-            for (int ch = 0; ch < F; ++ch) {
-                const float x = src[ch * PS];
-                a0 = fmaf(x, hp.pconv_w[ch * 2 + 0], a0);
-                a1 = fmaf(x, hp.pconv_w[ch * 2 + 1], a1);
-                av = fmaf(x, hp.vconv_w[ch], av);
-            }
-            scratch[lane] = fmaxf(a0 + hp.pconv_b[0], 0.f);        // flatten order (channel, cell): net.py:88
-            scratch[64 + lane] = fmaxf(a1 + hp.pconv_b[1], 0.f);
-            scratch[128 + lane] = fmaxf(av + hp.vconv_b[0], 0.f);
-        }
-        // policy FC + log_softmax: lane handles outputs lane and lane + 64
-        float l0 = -INFINITY, l1 = -INFINITY;
-        {
-            float s0 = lane < NP ? hp.pfc_b[lane] : 0.f;
-            float s1 = lane + 64 < NP ? hp.pfc_b[lane + 64] : 0.f;
-            for (int i = 0; i < 2 * CELLS; ++i) {
-                const float x = scratch[(i / CELLS) * 64 + (i % CELLS)];
-                if (lane < NP) s0 = fmaf(a.pfc_wt[(size_t)i * NP + lane], x, s0);
-                if (lane + 64 < NP) s1 = fmaf(a.pfc_wt[(size_t)i * NP + lane + 64], x, s1);
-            }
-            if (lane < NP) l0 = s0;
-            if (lane + 64 < NP) l1 = s1;
-        }
-        const float m = wave_max(fmaxf(l0, l1));
-        const float se = wave_sum((lane < NP ? expf(l0 - m) : 0.f) + (lane + 64 < NP ? expf(l1 - m) : 0.f));
-        const float lse = logf(se);
-        float* lp = logp + (pos0 + p) * NP;
-        if (lane < NP) lp[lane] = l0 - m - lse;
-        if (lane + 64 < NP) lp[lane + 64] = l1 - m - lse;
-        // value FC1 (256 outputs: 4 per lane) + ReLU + FC2 + tanh
-        float h[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = hp.vfc1_b[lane + 64 * j];
-        for (int i = 0; i < CELLS; ++i) {
-            const float x = scratch[128 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = fmaf(a.vfc1_wt[(size_t)i * 256 + lane + 64 * j], x, h[j]);
-        }
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part = fmaf(hp.vfc2_w[lane + 64 * j], fmaxf(h[j], 0.f), part);
-        const float tot = wave_sum(part);
-        if (lane == 0) vout[pos0 + p] = tanhf(tot + hp.vfc2_b[0]);
+        const int c = lane < CELLS ? lane : 0;
+        heads_wave<F, BS>(a.heads, a.pfc_wt, a.vfc1_wt, act + p * POSW + (c / BS + 1) * PW + (c % BS + 1), PS, scratch, lane,
+                          logp + (pos0 + p) * NP, vout + pos0 + p);
     }
 }
 

@@ -245,7 +245,7 @@ def test_net_forward_vs_reference_outputs(pkg, golden, seed):
     xd = torch.from_numpy(x).cuda()
     for nb, nf in NETS:
         tag, net = _golden_net(pkg, g, seed, nb, nf)
-        precs = ["f32"] + (["f16x3"] if nf == 128 else [])
+        precs = ["f32"] + (["f16x3"] if nf in (32, 64, 128) else [])
         for prec in precs:
             ev = pkg.HipResNetEvaluator(net, precision=prec)
             logp, v = ev.forward_planes(xd)
@@ -270,20 +270,25 @@ def test_net6_forward_vs_reference_outputs(pkg, golden, seed):
         net = pkg.OthelloResNet(nb, nf, board_size=6).eval()
         if (nb, nf) == (2, 16):
             net.load_state_dict({k: torch.from_numpy(g[tag + "_sd_" + k]) for k in net.state_dict()})
-        ev = pkg.HipResNetEvaluator(net)
-        assert ev.precision == "f32" and ev.policy_size == 37
-        logp, v = ev.forward_planes(xd)
-        assert tuple(logp.shape) == (len(xd), 37)
-        e1 = np.abs(logp.cpu().numpy() - g[tag + "_logp"]).max()
-        e2 = np.abs(v.cpu().numpy() - g[tag + "_v"]).max()
-        assert e1 < 1e-4 and e2 < 1e-4, (tag, e1, e2)
+        for prec in ["f32"] + (["f16x3"] if nf in (32, 64) else []):
+            ev = pkg.HipResNetEvaluator(net, precision=prec)
+            assert ev.policy_size == 37
+            logp, v = ev.forward_planes(xd)
+            assert tuple(logp.shape) == (len(xd), 37)
+            e1 = np.abs(logp.cpu().numpy() - g[tag + "_logp"]).max()
+            e2 = np.abs(v.cpu().numpy() - g[tag + "_v"]).max()
+            assert e1 < 1e-4 and e2 < 1e-4, (tag, prec, e1, e2)
+        assert pkg.HipResNetEvaluator(net).precision == ("f16x3" if nf in (32, 64) else "f32")
 
 
-@pytest.mark.parametrize("nb,nf,bs", [(2, 16, 8), (2, 32, 8), (5, 64, 8), (2, 128, 8), (5, 64, 6), (2, 16, 6),
-                                      (2, 32, 6), (2, 128, 6)])
-def test_f32_mfma_trunk_ragged_batches(pkg, nb, nf, bs):
-    """The exact-fp32 MFMA trunk (net_f32.hip) at batch sizes that leave waves, workgroups and tiles partly empty,
-    plus a 3000-position batch, vs torch fp32 on the same weights; and a device-side batch length (n_valid)."""
+@pytest.mark.parametrize("nb,nf,bs,prec", [(2, 16, 8, "f32"), (2, 32, 8, "f32"), (5, 64, 8, "f32"), (2, 128, 8, "f32"),
+                                           (5, 64, 6, "f32"), (2, 16, 6, "f32"), (2, 32, 6, "f32"), (2, 128, 6, "f32"),
+                                           (5, 64, 8, "f16x3"), (3, 32, 8, "f16x3"), (5, 64, 6, "f16x3"),
+                                           (3, 32, 6, "f16x3")])
+def test_f32_mfma_trunk_ragged_batches(pkg, nb, nf, bs, prec):
+    """The wave-per-position trunks -- exact fp32 MFMA (net_f32.hip) and the fp16-split one for 32 / 64 filters
+    (net_h3.hip) -- on trained-like weights at batch sizes that leave waves, workgroups and tiles partly empty, plus a
+    3000-position batch, vs torch fp32 on the same weights (1e-4); and a device-side batch length (n_valid)."""
     torch.manual_seed(1000 + nf + bs)
     net = pkg.OthelloResNet(nb, nf, board_size=bs).eval()
     g = torch.Generator().manual_seed(7)
@@ -293,7 +298,7 @@ def test_f32_mfma_trunk_ragged_batches(pkg, nb, nf, bs):
             mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
             mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
             mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
-    ev = pkg.HipResNetEvaluator(net, precision="f32")
+    ev = pkg.HipResNetEvaluator(net, precision=prec)
     rng = np.random.Generator(np.random.PCG64(5))
     for n in (1, 2, 3, 5, 7, 8, 9, 17, 33, 3000):
         occ = rng.random((n, bs, bs)) < 0.6
