@@ -347,7 +347,8 @@ def main():
         prec = ev.precision
         # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
         # source row is zero padding (1/12 of the conv work is skipped by the shipped kernel)
-        issued = (3.0 if prec == "f16x3" else 1.0) * (11.0 / 12.0 if prec != "f32" else 1.0)
+        wide = args.filters == 128 and args.board == 8     # k_trunk16 skips the all-padding tiles (1/12 of the work)
+        issued = (3.0 if prec == "f16x3" else 1.0) * (11.0 / 12.0 if (prec != "f32" and wide) else 1.0)
         peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
         evals_per_game = stats["evals"] / max(1, stats["games"])
         out = {
@@ -389,10 +390,12 @@ def main():
                 "timing_hooks_in_timed_region": False,
             },
             "roofline": {
-                "kernel": "k_trunk (fused ResNet forward)" if prec != "f32" else "k_trunk_f32 (fused ResNet forward, fp32 MFMA)",
+                "kernel": ("k_trunk_f32 (fused ResNet forward, fp32 MFMA)" if prec == "f32" else
+                           "k_trunk16 (fused ResNet forward)" if wide else
+                           "k_trunk_h3 (fused ResNet forward, one wave per position)"),
                 "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic if prec != "f32" else None,
+                "frac": round(achieved / peak, 4), "traffic": traffic if wide and prec != "f32" else None,
                 "traffic_basis": "PMC FETCH_SIZE/WRITE_SIZE of a full launch of 4096 positions "
                                  "(profiles/%s); algorithmic bytes of that launch: 1.18 MB" % traffic_file,
                 "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"
