@@ -36,7 +36,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
 
-MFLOP_PER_POSITION = 378.03     # 10x128 network, SURVEY.md 8(d) / BASELINE.md section 3
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak, MI355X_MICROARCH.md
 PLIES_PER_GAME = 60.7           # measured by the engine over >100k games of this workload

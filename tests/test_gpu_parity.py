@@ -452,12 +452,6 @@ def test_net_weight_refresh(pkg):
 
 
 # =========================================================================================== self-play
-def _load_g5_net(pkg, g, seed):
-    net = pkg.OthelloResNet(2, 16).eval()
-    net.load_state_dict({k: torch.from_numpy(g["net_s%d_sd_%s" % (seed, k)]) for k in net.state_dict()})
-    return net
-
-
 # (the episode-stream parity tests live in tests/test_gpu_selfplay_exact.py: exact, oracle driven by the HIP network)
 
 
