@@ -99,16 +99,45 @@ def cpu_baseline(net, sims, budget_s, evals_per_game):
 
 
 def proportional_shares(rates, nominal, lanes):
-    """Games per rank for the next step: proportional to the measured rates, within +-10 % of `nominal`, every share a
-    multiple of `lanes`, job total exactly len(rates) * nominal (the rounding remainder goes to the fastest rank)."""
+    """Games per rank for the next step: proportional to the measured rates, every share within +-10 % of `nominal`
+    and a multiple of `lanes`, job total exactly len(rates) * nominal.  Water-filling: ranks that hit a bound are fixed
+    there and the rest of the total is re-divided among the others in proportion to their rates."""
     import numpy as np
     rate = np.asarray(rates, dtype=np.float64)
     world = len(rate)
     if not np.all(np.isfinite(rate)) or rate.min() <= 0:
         return [nominal] * world
-    want = np.clip(nominal * world * rate / rate.sum(), 0.9 * nominal, 1.1 * nominal)
-    new = [int(w) // lanes * lanes for w in want]
-    new[int(np.argmax(rate))] += nominal * world - sum(new)
+    unit = lanes
+    lo = int(np.ceil(0.9 * nominal / unit)) * unit
+    hi = int(np.floor(1.1 * nominal / unit)) * unit
+    total = nominal * world
+    want = np.zeros(world)
+    free = np.ones(world, dtype=bool)
+    left = float(total)
+    for _ in range(world + 1):
+        if not free.any():
+            break
+        w = left * rate / rate[free].sum()
+        over, under = free & (w > hi), free & (w < lo)
+        if not over.any() and not under.any():
+            want[free] = w[free]
+            break
+        fix = over if over.any() else under     # one side at a time: fixing both at once can strand part of the total
+        want[fix] = hi if over.any() else lo
+        left -= want[fix].sum()
+        free &= ~fix
+    new = [int(w) // unit * unit for w in want]
+    # hand the rounding remainder out in units, fastest ranks first, never past the upper bound
+    rem = total - sum(new)
+    order = list(np.argsort(-rate))
+    i = 0
+    while rem >= unit and i < 4 * world:
+        r = order[i % world]
+        if new[r] + unit <= hi:
+            new[r] += unit
+            rem -= unit
+        i += 1
+    new[order[0]] += rem   # (only if every rank sits at the upper bound or nominal is not a multiple of the unit)
     return new
 
 

@@ -96,4 +96,10 @@ def test_bench_proportional_shares():
     assert bench.proportional_shares([1.0, 0.0], nominal, lanes) == [nominal, nominal]
     assert bench.proportional_shares([1.0, float("nan")], nominal, lanes) == [nominal, nominal]
     s = bench.proportional_shares([100.0, 300.0], nominal, lanes)   # clamp at +-10 %
-    assert sum(s) == 2 * nominal and min(s) >= int(0.9 * nominal) - lanes
+    assert sum(s) == 2 * nominal and min(s) >= int(0.9 * nominal) - lanes and max(s) <= 1.1 * nominal + lanes
+    # one fast rank among slow ones: nobody leaves the +-10 % band (the rest is re-divided among the others)
+    for rates2 in ([100.0] * 7 + [300.0], [300.0] * 7 + [100.0], [1.0, 1.02, 0.97, 5.0], [3006.0, 966.0, 949.0, 4000.0]):
+        for nom, ln in ((1536, 2), (64, 2), (12288, 2), (2048, 1)):
+            s2 = bench.proportional_shares(rates2, nom, ln)
+            assert sum(s2) == nom * len(rates2) and all(x % ln == 0 for x in s2)
+            assert min(s2) >= 0.9 * nom - ln and max(s2) <= 1.1 * nom + ln, (rates2, nom, s2)
