@@ -185,6 +185,10 @@ def main():
     ap.add_argument("--equal-shares", action="store_true",
                     help="N>1: every rank targets exactly --step-games per step instead of rate-proportional shares")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps after the timed region with HIP-event hooks on")
+    ap.add_argument("--hooks-always", action="store_true",
+                    help="keep the HIP-event hooks on for EVERY step (warm-up and timed region too) and report the mean "
+                         "trunk launch duration over all launches of the run: the figure a rocprofv3 --kernel-trace "
+                         "--stats of the same command must reproduce.  Not the headline configuration.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     args = ap.parse_args()
@@ -296,6 +300,18 @@ def main():
         rebalance(games, t_play)
         return games, samples
 
+    all_launch = {"ms": 0.0, "n": 0}
+    if args.hooks_always:
+        for e_ in engs:
+            e_.set_timing(True)
+
+    def tally_launches():
+        if args.hooks_always:
+            for e_ in engs:
+                kt = e_.kernel_time()
+                all_launch["ms"] += kt["net_ms"]
+                all_launch["n"] += kt["net_launches"]
+
     def counters():
         tot = {}
         for e_ in engs:
@@ -309,6 +325,7 @@ def main():
     for i in range(args.warmup):
         t1 = time.time()
         g, _ = step()
+        tally_launches()
         beat("warm-up step %d/%d: %d games in %.2f s" % (i + 1, args.warmup, g, time.time() - t1))
     barrier()
     c0 = counters()
@@ -317,6 +334,7 @@ def main():
     for i in range(args.steps):
         t1 = time.time()
         g, samples = step()
+        tally_launches()
         my_games += g
         beat("step %d/%d: %d games in %.2f s (%.1f games/s this rank, %.1f cumulative)"
              % (i + 1, args.steps, g, time.time() - t1, g / max(time.time() - t1, 1e-9), my_games / (time.time() - t0)))
@@ -342,6 +360,7 @@ def main():
             cp0 = counters()
             t1 = time.time()
             g, _ = step()
+            tally_launches()
             prof["wall_s"] += time.time() - t1
             prof["games"] += g
             cp1 = counters()
@@ -415,7 +434,7 @@ def main():
                 "samples_last_step": samples,
                 "evals_per_game": round(evals_per_game, 1),
                 "plies_per_game": round(stats["plies"] / max(1, stats["games"]), 2),
-                "timing_hooks_in_timed_region": False,
+                "timing_hooks_in_timed_region": bool(args.hooks_always),
             },
             "roofline": {
                 "kernel": ("k_trunk_f32 (fused ResNet forward, fp32 MFMA)" if prec == "f32" else
@@ -431,6 +450,9 @@ def main():
                 "frac_mfma_issue": round(achieved * issued / peak, 4),
                 "launches": prof["net_launches"],
                 "avg_launch_ms": round(prof["net_ms"] / max(1, prof["net_launches"]), 4),
+                "avg_launch_ms_all_launches": (round(all_launch["ms"] / max(1, all_launch["n"]), 4)
+                                               if args.hooks_always else None),
+                "launches_all": all_launch["n"] if args.hooks_always else None,
                 "busy_ms": round(prof["union_ms"], 1), "concurrent_lanes": lanes,
                 "time_basis": "union of the HIP-event intervals of all k_trunk launches (the %d lanes' launches "
                               "overlap; sum of launch durations = %.0f ms)" % (lanes, prof["net_ms"]),
