@@ -25,6 +25,11 @@ def _wants_gpu(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (the .so is git-ignored): build it once, as __graft_entry__.build() does
+    lib = os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "libothello_mi355x.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j4", "-C",
+                               os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "csrc")])
 
 
 def pytest_sessionstart(session):
