@@ -66,6 +66,8 @@ class DistributedSelfPlayWorker:
     def execute_episodes_tensors(self, num_episodes, add_dirichlet_noise=True):
         """-> CUDA tensors (states, pis, zs) of the WHOLE job, plus per-rank tuple counts."""
         mine = shard_episodes(num_episodes, self.rank, self.world_size)
+        if hasattr(self.worker, "_grow_engine"):
+            self.worker._grow_engine(mine)   # auto slot width: the whole share at once (results do not depend on it)
         eng = self.worker.engine
         self.worker.batch_mcts.evaluator.refresh()
         seed = (self.base_seed + 0x9E3779B97F4A7C15 * (self._calls * self.world_size + self.rank + 1)) % 2**63

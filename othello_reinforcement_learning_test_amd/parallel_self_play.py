@@ -75,7 +75,7 @@ class ParallelSelfPlayWorker:
     def __init__(self, board_class, model, device=None, num_simulations=25, temperature_threshold=15,
                  num_parallel_games=8, c_puct=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
                  rng_mode=None, precision=None, verbose=True, eval_cache_log2=0, lanes=None, continuous=False,
-                 stagger_rounds=0):
+                 stagger_rounds=0, device_slots=None):
         self.board_class = board_class
         self.num_simulations = num_simulations
         self.temperature_threshold = temperature_threshold
@@ -86,7 +86,17 @@ class ParallelSelfPlayWorker:
         self.verbose = verbose
         self.batch_mcts = BatchMCTS(model, device, c_puct, dirichlet_alpha, dirichlet_epsilon,
                                     precision=precision)
-        self.engine = SearchEngine(num_parallel_games, num_simulations,
+        # device_slots: game slots of the engine in device-RNG mode.  The reference's num_parallel_games (8-32 in its
+        # configs, parallel_self_play.py:232) is how many games share one network batch; with the counter-based RNG a
+        # game's tuples depend on (seed, game id) only, so playing MORE games of a call at once changes nothing but the
+        # speed (42 games/s at 8 slots, >500 at 128).  None = as many slots as a call has episodes, at least
+        # num_parallel_games and at most 4096 (the engine grows on demand); an int pins it (num_parallel_games = the
+        # reference's width).  The numpy-RNG mode always plays num_parallel_games lock-step games, as the reference does.
+        self.device_slots = None if device_slots is None else int(device_slots)
+        self._engine_args = dict(temperature_threshold=temperature_threshold, c_puct=c_puct,
+                                 dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
+                                 store_late_onehot=False, eval_cache_log2=eval_cache_log2)
+        self.engine = SearchEngine(self.device_slots or num_parallel_games, num_simulations,
                                    temperature_threshold=temperature_threshold, c_puct=c_puct,
                                    dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
                                    store_late_onehot=False, evaluator=self.batch_mcts.evaluator,
@@ -119,9 +129,22 @@ class ParallelSelfPlayWorker:
         self._ran = [self.engine]   # engines the last device-RNG call ran on
 
     # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------
+    def _grow_engine(self, num_episodes):
+        """Auto mode: make the single engine wide enough to play the whole call at once (power of two, <= 4096)."""
+        if self.device_slots is not None:
+            return
+        want = self.num_parallel_games
+        while want < min(int(num_episodes), 4096):
+            want *= 2
+        want = min(want, max(4096, self.num_parallel_games))
+        if want > self.engine.max_games:
+            self.engine = SearchEngine(want, self.num_simulations, evaluator=self.batch_mcts.evaluator,
+                                       **self._engine_args)
+
     def _run_device(self, num_episodes, add_dirichlet_noise):
         seed = int(np.random.randint(0, 2**62))
         if self.lanes == 1 or num_episodes < 2 * self.lanes:
+            self._grow_engine(num_episodes)
             self._ran = [self.engine]
             n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
             return self.engine.selfplay_fetch(n)[:3]
@@ -237,6 +260,7 @@ class ParallelSelfPlayWorker:
         self.batch_mcts.evaluator.refresh()
         if seed is None:
             seed = int(np.random.randint(0, 2**62))
+        self._grow_engine(num_episodes)
         n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
         return self.engine.selfplay_fetch(n)[:3]
 

@@ -503,7 +503,7 @@ def test_selfplay_device_rng_properties(pkg):
     torch.manual_seed(3)
     net = pkg.OthelloResNet(2, 16).eval()
     w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=6, temperature_threshold=8,
-                                   num_parallel_games=16, verbose=False)
+                                   num_parallel_games=16, verbose=False, device_slots=16)
     np.random.seed(0)
     data = w.execute_episodes(40)            # 40 games through 16 slots: refill path
     assert isinstance(data, list) and isinstance(data[0], tuple)
@@ -524,6 +524,14 @@ def test_selfplay_device_rng_properties(pkg):
                for a, b in zip(data, again))
     other = w.execute_episodes(40)
     assert len(other) != len(data) or any(not np.array_equal(a[0], b[0]) for a, b in zip(data, other))
+    # the slot count is a speed knob only: the default (engine grown to the call's 40 episodes -> 64 slots, no refill)
+    # returns the same tuples as the 16-slot engine for the same seed
+    w_auto = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=6, temperature_threshold=8,
+                                        num_parallel_games=16, verbose=False)
+    np.random.seed(0)
+    wide = w_auto.execute_episodes(40)
+    assert w_auto.engine.max_games == 64 and len(wide) == len(data)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(data, wide))
 
 
 def test_selfplay_400_sims_deep_trees(pkg):
