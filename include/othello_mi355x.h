@@ -100,8 +100,8 @@ int oth_rules_checksum_n(int board_size, int64_t n, uint64_t *legal_acc /*HOST*/
  * =========================================================================================== */
 typedef struct oth_net oth_net;
 #define OTH_PREC_F32 0     /* exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32): 16/32/64/128 filters, 8x8 and 6x6 */
-#define OTH_PREC_F16X3 1   /* MFMA, fp16 hi/lo split of both operands, fp32 accumulate (fp32-equivalent): 128 filters on
-                              8x8, 32 / 64 filters on 8x8 and 6x6 */
+#define OTH_PREC_F16X3 1   /* MFMA, fp16 hi/lo split of both operands, fp32 accumulate (fp32-equivalent): 32 / 64 / 128
+                              filters on 8x8 and 6x6 */
 #define OTH_PREC_F16 2     /* MFMA, single fp16 pass (fast; NOT within the 1e-4 parity tolerance in general); 128 filters, 8x8 */
 
 /* net.py:157-180 __init__(num_blocks, num_filters, board_size).  board_size 8 or 6 (configs/debug_6x6.yaml);

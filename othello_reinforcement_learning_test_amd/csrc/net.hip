@@ -133,7 +133,7 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
     // fp16-split kernels: 128 filters on 8x8 (k_trunk16: f16x3 and the single-pass f16), 32 / 64 filters on either
     // board (k_trunk_h3: f16x3 only); everything else runs the exact-fp32 MFMA kernel
     const bool wide = net->filters == 128 && net->board == 8;
-    const bool narrow = net->filters == 32 || net->filters == 64;
+    const bool narrow = net->filters == 32 || net->filters == 64 || (net->filters == 128 && net->board == 6);
     if (precision != OTH_PREC_F32 && !(wide || (narrow && precision == OTH_PREC_F16X3))) {
         set_error("oth_net_load_state: no fp16-split kernel for %d filters on a %dx%d board at precision %d; use "
                   "OTH_PREC_F32 (exact fp32 MFMA)", net->filters, net->board, net->board, precision);
@@ -158,7 +158,7 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
     const float* d = net->d_heads;
     net->heads = HeadParams{d + o_pw, d + o_pb, d + o_vw, d + o_vb, d + o_pfw, d + o_pfb, d + o_v1w, d + o_v1b, d + o_v2w, d + o_v2b};
     int r = precision == OTH_PREC_F32 ? f32_pack_weights(net)
-                                      : (net->filters == 128 ? mfma_pack_weights(net, precision) : h3_pack_weights(net));
+                                      : (wide ? mfma_pack_weights(net, precision) : h3_pack_weights(net));
     if (r != OTH_OK) return r;
     net->precision = precision;
     return OTH_OK;

@@ -298,7 +298,8 @@ static float pack_layer_h3(const FoldedConv& c, int F, int kk_steps, std::vector
 int h3_pack_weights(oth_net* net) {
     const HostNet& hn = net->host;
     const int F = hn.filters, L = 1 + 2 * hn.blocks, cells = net->board * net->board, NP = cells + 1;
-    OTH_CHECK(F == 32 || F == 64, "the wave-per-position fp16-split trunk is built for 32 and 64 filters");
+    OTH_CHECK(F == 32 || F == 64 || (F == 128 && net->board == 6),
+              "the wave-per-position fp16-split trunk is built for 32 and 64 filters (and 128 on 6x6)");
     OTH_CHECK(L <= kMaxTrunkLayers, "too many layers");
     H3Weights* hw = new H3Weights();
     net->h3 = hw;
@@ -371,6 +372,7 @@ int h3_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uint6
     OTH_H3_CASE(32, 8, 1, 4);
     OTH_H3_CASE(64, 6, 2, 4);
     OTH_H3_CASE(32, 6, 4, 4);
+    OTH_H3_CASE(128, 6, 1, 4);   // 128 filters on 6x6 (8x8 has k_trunk16; its planes would not fit four waves here)
 #undef OTH_H3_CASE
     set_error("fp16-split wave trunk: unsupported filters %d / board %d", F, net->board);
     return OTH_E_UNSUPPORTED;

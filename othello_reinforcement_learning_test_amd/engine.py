@@ -11,10 +11,10 @@ from . import _lib
 
 def default_precision(num_filters, board_size=8):
     """fp16-split MFMA trunks (fp32-equivalent: three f16 products per operand pair) where one exists -- 128 filters on
-    8x8 (k_trunk16, the benchmarked kernel), 32 / 64 filters on 8x8 and 6x6 (k_trunk_h3) -- else the exact-fp32 MFMA
-    trunk (16 filters; 128 filters on 6x6)."""
-    if num_filters == 128 and board_size == 8:
-        return "f16x3"
+    8x8 (k_trunk16, the benchmarked kernel), 32 / 64 filters on 8x8 and 6x6 and 128 filters on 6x6 (k_trunk_h3) -- else
+    the exact-fp32 MFMA trunk (16 filters)."""
+    if num_filters == 128:
+        return "f16x3"     # 8x8: k_trunk16; 6x6: k_trunk_h3
     return "f16x3" if num_filters in (32, 64) else "f32"
 
 

@@ -270,7 +270,7 @@ def test_net6_forward_vs_reference_outputs(pkg, golden, seed):
         net = pkg.OthelloResNet(nb, nf, board_size=6).eval()
         if (nb, nf) == (2, 16):
             net.load_state_dict({k: torch.from_numpy(g[tag + "_sd_" + k]) for k in net.state_dict()})
-        for prec in ["f32"] + (["f16x3"] if nf in (32, 64) else []):
+        for prec in ["f32"] + (["f16x3"] if nf in (32, 64, 128) else []):
             ev = pkg.HipResNetEvaluator(net, precision=prec)
             assert ev.policy_size == 37
             logp, v = ev.forward_planes(xd)
@@ -278,14 +278,14 @@ def test_net6_forward_vs_reference_outputs(pkg, golden, seed):
             e1 = np.abs(logp.cpu().numpy() - g[tag + "_logp"]).max()
             e2 = np.abs(v.cpu().numpy() - g[tag + "_v"]).max()
             assert e1 < 1e-4 and e2 < 1e-4, (tag, prec, e1, e2)
-        assert pkg.HipResNetEvaluator(net).precision == ("f16x3" if nf in (32, 64) else "f32")
+        assert pkg.HipResNetEvaluator(net).precision == ("f16x3" if nf in (32, 64, 128) else "f32")
 
 
 @pytest.mark.parametrize("nb,nf,bs,prec", [(2, 16, 8, "f32"), (2, 32, 8, "f32"), (5, 64, 8, "f32"), (2, 128, 8, "f32"),
                                            (5, 64, 6, "f32"), (2, 16, 6, "f32"), (2, 32, 6, "f32"), (2, 128, 6, "f32"),
                                            (5, 64, 8, "f16x3"), (3, 32, 8, "f16x3"), (5, 64, 6, "f16x3"),
-                                           (3, 32, 6, "f16x3")])
-def test_f32_mfma_trunk_ragged_batches(pkg, nb, nf, bs, prec):
+                                           (3, 32, 6, "f16x3"), (2, 128, 6, "f16x3")])
+def test_wave_trunks_ragged_batches(pkg, nb, nf, bs, prec):
     """The wave-per-position trunks -- exact fp32 MFMA (net_f32.hip) and the fp16-split one for 32 / 64 filters
     (net_h3.hip) -- on trained-like weights at batch sizes that leave waves, workgroups and tiles partly empty, plus a
     3000-position batch, vs torch fp32 on the same weights (1e-4); and a device-side batch length (n_valid)."""

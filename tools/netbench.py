@@ -14,7 +14,7 @@ import othello_reinforcement_learning_test_amd as pkg  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--nets", default="10x128x8:f16x3,10x128x8:f16,10x128x8:f32,5x64x8:f16x3,5x64x8:f32,2x32x8:f16x3,"
-                                  "2x32x8:f32,2x16x8:f32,5x64x6:f16x3,5x64x6:f32,2x32x6:f16x3,2x16x6:f32")
+                                  "2x32x8:f32,2x16x8:f32,5x64x6:f16x3,5x64x6:f32,2x32x6:f16x3,2x16x6:f32,3x128x6:f16x3,3x128x6:f32")
 args = ap.parse_args()
 N = args.n
 rng = np.random.Generator(np.random.PCG64(0))
