@@ -117,7 +117,8 @@ class OthelloBitboard:
 
 class DeviceBoards:
     """The same rules over arrays of positions on the GPU (torch int64 tensors holding the uint64
-    bit patterns).  Thin wrappers over section 2 of the C ABI."""
+    bit patterns).  Thin wrappers over section 2 of the C ABI.  ``board_size=6`` selects the 6x6 rules (bit i =
+    row*6+col, pass 36, planes [3,6,6]; parity unpinned -- the reference has no 6x6 game)."""
 
     @staticmethod
     def _args(*tensors):
@@ -129,37 +130,38 @@ class DeviceBoards:
         return torch
 
     @staticmethod
-    def legal_moves(self_b, opp_b):
+    def legal_moves(self_b, opp_b, board_size=8):
         torch = DeviceBoards._args(self_b, opp_b)
         out = torch.empty_like(self_b)
-        _lib.call("oth_legal_moves_batch", self_b.data_ptr(), opp_b.data_ptr(), out.data_ptr(),
+        _lib.call("oth_legal_moves_batch_n", int(board_size), self_b.data_ptr(), opp_b.data_ptr(), out.data_ptr(),
                   self_b.numel(), _lib.current_stream())
         return out
 
     @staticmethod
-    def make_move(self_b, opp_b, pos):
+    def make_move(self_b, opp_b, pos, board_size=8):
         """In place.  Returns (ok int32[n], flips int64[n])."""
         torch = DeviceBoards._args(self_b, opp_b, pos)
         ok = torch.empty(self_b.numel(), dtype=torch.int32, device=self_b.device)
         flips = torch.empty_like(self_b)
-        _lib.call("oth_make_move_batch", self_b.data_ptr(), opp_b.data_ptr(), pos.data_ptr(),
+        _lib.call("oth_make_move_batch_n", int(board_size), self_b.data_ptr(), opp_b.data_ptr(), pos.data_ptr(),
                   ok.data_ptr(), flips.data_ptr(), self_b.numel(), _lib.current_stream())
         return ok, flips
 
     @staticmethod
-    def status(self_b, opp_b):
+    def status(self_b, opp_b, board_size=8):
         """-> (terminal int32[n], winner int32[n])"""
         torch = DeviceBoards._args(self_b, opp_b)
         term = torch.empty(self_b.numel(), dtype=torch.int32, device=self_b.device)
         win = torch.empty_like(term)
-        _lib.call("oth_status_batch", self_b.data_ptr(), opp_b.data_ptr(), term.data_ptr(),
+        _lib.call("oth_status_batch_n", int(board_size), self_b.data_ptr(), opp_b.data_ptr(), term.data_ptr(),
                   win.data_ptr(), self_b.numel(), _lib.current_stream())
         return term, win
 
     @staticmethod
-    def tensor_input(self_b, opp_b):
+    def tensor_input(self_b, opp_b, board_size=8):
         torch = DeviceBoards._args(self_b, opp_b)
-        out = torch.empty((self_b.numel(), 3, 8, 8), dtype=torch.float32, device=self_b.device)
-        _lib.call("oth_tensor_input_batch", self_b.data_ptr(), opp_b.data_ptr(), out.data_ptr(),
+        bs = int(board_size)
+        out = torch.empty((self_b.numel(), 3, bs, bs), dtype=torch.float32, device=self_b.device)
+        _lib.call("oth_tensor_input_batch_n", bs, self_b.data_ptr(), opp_b.data_ptr(), out.data_ptr(),
                   self_b.numel(), _lib.current_stream())
         return out

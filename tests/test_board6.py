@@ -106,9 +106,9 @@ def test_device_rules_6x6_vs_oracle6(pkg):
     import torch
     s, o = random_positions6(200_000, 5)
     ds, do = dev_u64(s), dev_u64(o)
-    lg = torch.empty_like(ds)
-    pkg._lib.call("oth_legal_moves_batch_n", 6, ds.data_ptr(), do.data_ptr(), lg.data_ptr(), len(s), None)
+    lg = pkg.DeviceBoards.legal_moves(ds, do, board_size=6)
     assert np.array_equal(lg.cpu().numpy().view(U64), o6.legal_batch(s, o))
+    assert tuple(pkg.DeviceBoards.tensor_input(ds[:5], do[:5], board_size=6).shape) == (5, 3, 6, 6)
     term = torch.empty(len(s), dtype=torch.int32, device="cuda")
     win = torch.empty(len(s), dtype=torch.int32, device="cuda")
     pkg._lib.call("oth_status_batch_n", 6, ds.data_ptr(), do.data_ptr(), term.data_ptr(), win.data_ptr(), len(s), None)
