@@ -153,8 +153,10 @@ typedef struct {
                                   skips re-evaluating positions the search has already evaluated (no reference
                                   counterpart: the reference re-evaluates; outputs are identical) */
     int32_t board_size;        /* 0 or 8: the reference's 8x8 game.  6: the same engine on a 6x6 board (BASELINE
-                                  configs[4]): pass action 36, policies of 37, states [3,6,6]; rules as oth_*_n(6, ...)
-                                  define them -- PARITY UNPINNED, the reference has no 6x6 rules */
+                                  configs[4]): pass action 36; every [.,65] array below is [.,37] and every
+                                  [.,3,8,8] array [.,3,6,6]; rules as oth_*_n(6, ...) define them -- PARITY
+                                  UNPINNED, the reference has no 6x6 rules.  The network given to
+                                  oth_engine_set_net must have been created for the same board size. */
 } oth_engine_cfg;
 
 oth_engine *oth_engine_create(const oth_engine_cfg *cfg);
