@@ -194,6 +194,10 @@ def main():
     args = ap.parse_args()
 
     t_start = time.time()
+    if not args.no_cpu_baseline:   # (re)build the CPU oracle now: no fork+exec once this process holds the GPU
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        oracle_lib.build()
     import numpy as np  # noqa: F401
     import torch
 
@@ -290,10 +294,8 @@ def main():
         parts = [e_.selfplay_device_tensors() for e_ in engs]
         t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
-            st, pi, z = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
-            if gloo:
-                st, pi, z = st.cpu(), pi.cpu(), z.cpu()
-            st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)
+            st, pi, z = ([p_[j].cpu() if gloo else p_[j] for p_ in parts] for j in range(3))   # one part per lane
+            st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)   # persistent buffers: no per-step allocation
             samples = int(z.shape[0])
         else:          # single GPU: the tuples stay where the lanes compacted them (no copy)
             samples = sum(int(p_[2].shape[0]) for p_ in parts)
@@ -414,8 +416,9 @@ def main():
                       "f32": "f32 (exact fp32 on v_mfma_f32_16x16x4_f32)"}[prec],
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d, %d sims/move, %d-block x %d ResNet, %d concurrent games on 1 MI355X per rank%s"
+                "workload": "%dx%d, %d sims/move, %d-block x %d ResNet, %d concurrent games %s%s"
                             % (args.board, args.board, args.sims, args.blocks, args.filters, args.games,
+                               "per rank, ranks SHARING one MI355X (gloo rehearsal)" if gloo else "on 1 MI355X per rank",
                                "" if args.board == 8 else " -- 6x6 RULES PARITY UNPINNED (the reference implements no 6x6 "
                                "game; checked against the 6x6 build of the CPU oracle only)"),
                 "step": "steady-state streaming: a step ends when >= %d more games per GPU have finished (slots stay "
@@ -423,8 +426,10 @@ def main():
                 "games_timed": total_games, "concurrent_games_per_gpu": args.games,
                 "weights": "seeded random init (torch.manual_seed(42)), eval mode",
                 "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
-                "parallelism": "dp%d: games sharded, %s" % (world, "RCCL all-gather of replay tuples per step"
-                                                            if world > 1 else "single GPU"),
+                "parallelism": "dp%d: games sharded, %s" % (
+                    world, "single GPU" if not use_dist else
+                    ("gloo all-gather of replay tuples per step on host copies (REHEARSAL: several ranks share one GPU; "
+                     "not a multi-GPU measurement)" if gloo else "RCCL all-gather of replay tuples per step")),
                 "lanes_per_gpu": lanes,
                 "step_targets_last_step": ("equal" if world == 1 or args.equal_shares else
                                            "proportional to each rank's measured rate in the previous step "

@@ -125,6 +125,11 @@ int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *o
                          int64_t n, const int32_t *n_valid, float *logp, float *v, void *stream);
 /* forward(x) for x float32 [n,3,S,S] holding 0/1 planes (the reference's input format) DEVICE */
 int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
+/* The fp16-split trunk kernels (OTH_PREC_F16X3 / OTH_PREC_F16) clamp activations to 3750 (the f16 range of the hi
+ * parts after the 2^4 pre-scale); the reference's fp32 forward (net.py:182-205) does not.  *flag = 1 when any launch
+ * since the last call clamped a value -- the results then differ from the reference: reload the weights with
+ * OTH_PREC_F32.  Reads and clears a device flag; synchronises `stream`.  HOST flag. */
+int oth_net_saturated(oth_net *net, int32_t *flag, void *stream);
 
 /* probs[i] = exp(logp[i]) exactly as the engine's expansion computes it from the network's log-probabilities
  * (mcts.py:189 / parallel_self_play.py:72-76 `policy_probs = torch.exp(policy_logits)`): lets an external
@@ -182,7 +187,8 @@ int oth_search_expand(oth_engine *e, const float *policy, const float *value, in
 /* begin(already called) + num_simulations x (select, network, expand) with the engine's network */
 int oth_search_run(oth_engine *e, void *stream);
 /* Results per root i.  Synchronous.  Any output may be NULL.  HOST.
- *   pi[n,65]      node.py:147 get_policy_distribution(temperature); temperature 0 or 1
+ *   pi[n,65]      node.py:147 get_policy_distribution(temperature); temperature 0 or 1 (any other value is an
+ *                 error here: the Python mirror evaluates node.py:175-177's counts ** (1/T) on the host from visits[])
  *   visits[n,65]  child visit counts;  value_sum[n,65] child W (float64);  prior[n,65] child P */
 int oth_search_results(oth_engine *e, double temperature, float *pi, int32_t *visits, double *value_sum,
                        float *prior, void *stream);
@@ -265,6 +271,14 @@ int oth_augment_symmetries(const float *states, const float *pis, const float *z
 int oth_replay_gather(const float *states, const float *pis, const float *zs, const int64_t *idx, int64_t n,
                       int64_t ring_start, int64_t ring_size, float *states_out, float *pis_out, float *values_out,
                       void *stream);
+
+/* The same two operations for a board of board_size x board_size squares (8 or 6): rows of [3,S,S] / [S*S+1] floats
+ * (OthelloResNet is size-parametric, /root/reference/src/model/net.py:81,116; BASELINE configs[4] plays 6x6). */
+int oth_augment_symmetries_n(int board_size, const float *states, const float *pis, const float *zs, int64_t n,
+                             float *states_out, float *pis_out, float *zs_out, void *stream);
+int oth_replay_gather_n(int board_size, const float *states, const float *pis, const float *zs, const int64_t *idx,
+                        int64_t n, int64_t ring_start, int64_t ring_size, float *states_out, float *pis_out,
+                        float *values_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -478,7 +478,10 @@ static void tree_policy(const t_tree *t, double temperature, float *pi65) {
     float counts[ORC_NPOL], total;
     for (int i = 0; i < root->n_children; ++i) {
         float c = (float)t->edges[root->first_edge + i].visit_count;
-        counts[i] = temperature == 1.0 ? c : powf(c, (float)(1.0 / temperature));
+        /* counts ** (1.0 / temperature) on a float32 array (node.py:175): numpy keeps float32 and takes its scalar-power
+         * fast paths -- exponent 2.0 is np.square, 0.5 is np.sqrt (both correctly rounded) -- and powf otherwise */
+        const double ex = 1.0 / temperature;
+        counts[i] = ex == 1.0 ? c : (ex == 2.0 ? c * c : (ex == 0.5 ? sqrtf(c) : powf(c, (float)ex)));
     }
     total = np_sum_f32(counts, root->n_children);
     for (int i = 0; i < root->n_children; ++i)

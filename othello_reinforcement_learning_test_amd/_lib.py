@@ -73,6 +73,7 @@ _SIGS = {
     "oth_net_load_state": (C.c_int, [vp, f32p, C.c_int64, C.c_int]),
     "oth_net_forward_bits": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
     "oth_net_forward_planes": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
+    "oth_net_saturated": (C.c_int, [vp, i32p, vp]),
     "oth_policy_exp": (C.c_int, [vp, vp, C.c_int64, vp]),
     "oth_engine_create": (vp, [C.POINTER(EngineCfg)]),
     "oth_engine_destroy": (None, [vp]),
@@ -99,6 +100,8 @@ _SIGS = {
     "oth_engine_net_spans": (C.c_int, [vp, f64p, C.c_int64, i64p]),
     "oth_replay_gather": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "oth_augment_symmetries": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
+    "oth_replay_gather_n": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp]),
+    "oth_augment_symmetries_n": (C.c_int, [C.c_int, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
 }
 _PLAIN_INT = {"oth_device_available", "oth_net_policy_size", "oth_board_make_move_n", "oth_board_is_terminal_n", "oth_board_make_move", "oth_board_is_terminal", "oth_board_get_winner"}
 

@@ -54,6 +54,7 @@ struct oth_net {
     int precision = -1;  // OTH_PREC_*; -1 = no weights loaded
     oth::HostNet host;
     float* d_heads = nullptr;  // one allocation: the fp32 head parameters (shared by both trunk kernels)
+    int* d_sat = nullptr;      // device flag: an fp16-split trunk kernel clamped an activation (oth_net_saturated)
     oth::HeadParams heads{};
     // exact-fp32 MFMA path (any filter count, 8x8 and 6x6): net_f32.hip
     oth::F32Weights* f32 = nullptr;

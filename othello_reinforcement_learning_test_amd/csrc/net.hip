@@ -82,6 +82,8 @@ using namespace oth;
 static void net_free_device(oth_net* net) {
     if (net->d_heads) (void)hipFree(net->d_heads);
     net->d_heads = nullptr;
+    if (net->d_sat) (void)hipFree(net->d_sat);
+    net->d_sat = nullptr;
     f32_free_weights(net);
     h3_free_weights(net);
     mfma_free_weights(net);
@@ -115,6 +117,21 @@ void oth_net_destroy(oth_net* net) {
     (void)bind_device(net->device);
     net_free_device(net);
     delete net;
+}
+
+int oth_net_saturated(oth_net* net, int32_t* flag, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(net && flag, "oth_net_saturated: null argument");
+    *flag = 0;
+    if (!net->d_sat) return OTH_OK;   // no weights loaded yet
+    OTH_BIND(net->device);
+    hipStream_t s = as_stream(stream);
+    int v = 0;
+    OTH_HIP(hipMemcpyAsync(&v, net->d_sat, sizeof(int), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    if (v) OTH_HIP(hipMemsetAsync(net->d_sat, 0, sizeof(int), s));
+    *flag = v;
+    return OTH_OK;
 }
 
 int64_t oth_net_state_floats(const oth_net* net) { return net ? state_floats(net->blocks, net->filters, net->board) : 0; }
@@ -153,6 +170,8 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
     const size_t o_pw = push(h.pconv.w), o_pb = push(h.pconv.bias), o_vw = push(h.vconv.w), o_vb = push(h.vconv.bias);
     const size_t o_pfw = push(h.pfc_w), o_pfb = push(h.pfc_b), o_v1w = push(h.vfc1_w), o_v1b = push(h.vfc1_b);
     const size_t o_v2w = push(h.vfc2_w), o_v2b = push(h.vfc2_b);
+    OTH_HIP(hipMalloc(&net->d_sat, sizeof(int)));
+    OTH_HIP(hipMemset(net->d_sat, 0, sizeof(int)));
     OTH_HIP(hipMalloc(&net->d_heads, flat.size() * sizeof(float)));
     OTH_HIP(hipMemcpy(net->d_heads, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* d = net->d_heads;

@@ -55,6 +55,7 @@ struct H3Args {
     HeadParams heads;
     const float* pfc_wt;
     const float* vfc1_wt;
+    int* sat;   // set to 1 when an activation reaches the clamp (oth_net_saturated)
 };
 
 template <int F, int BS, int P>
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
             res[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+    uint32_t sat_bits = 0;   // largest activation seen (bit pattern); reaching the clamp raises the saturation flag
     for (int layer = 0; layer < a.n_layers; ++layer) {
         const int KK = layer == 0 ? 1 : F / 32;   // k-steps of 32 input channels (stem: planes 0..2 of chunk 0)
         const int nsteps = 9 * KK;
@@ -206,6 +208,8 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                 if (add_res) v += res[b][t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, 60000.f);  // ReLU + f16 range clamp
+                sat_bits = max(sat_bits, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])),
+                                             max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
                 if (set_res) res[b][t] = v;
                 acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (valid[t]) {
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 
     // ---- heads: the final activations (in `res`, scaled by 2^4) as fp32 planes [channel][output cell], aliasing
     //      the activation arrays (every read of them is done)
+    if (sat_bits >= __float_as_uint(60000.f)) atomicOr(a.sat, 1);   // rare: surfaced by oth_net_saturated
     float* planes = (float*)act;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -365,6 +370,7 @@ int h3_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uint6
     a.heads = net->heads;
     a.pfc_wt = net->h3->d_pfc_wt;
     a.vfc1_wt = net->h3->d_vfc1_wt;
+    a.sat = net->d_sat;
     const int F = net->filters;
 #define OTH_H3_CASE(FF, BB, PP, WW) \
     if (F == FF && net->board == BB) return launch_h3<FF, BB, PP, WW>(net, a, sb, ob, lg, n, n_valid, logp, v, stream)

@@ -51,6 +51,7 @@ constexpr int kZeroOff = kActBytes;            // zero cell (512 B)
 constexpr int kScratchOff = kActBytes + 512;   // stem im2col (16 KiB) / head scratch
 constexpr int kLdsBytes = kScratchOff + 16384;
 constexpr float kActScale = 16.0f;             // 2^4
+constexpr float kActClamp = 60000.0f;          // activations are clamped to 60000 / 16 = 3750 (the f16 range of the hi parts)
 
 struct MfmaWeights {
     int blocks = 0;
@@ -69,6 +70,8 @@ struct MfmaArgs {
     int n_res_layers;  // 2 * blocks
     HeadParams heads;
     unsigned long long* dbg;  // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
+    unsigned long long* tl;   // diagnostic build only: per-layer conv start / end of workgroups 0 and 256
+    int* sat;                 // set to 1 when an activation reaches the clamp (oth_net_saturated)
 };
 
 #ifdef OTH_STAMPS
@@ -77,6 +80,13 @@ __device__ __forceinline__ unsigned long long oth_clk() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ unsigned long long oth_realclk() {   // 100 MHz constant clock
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     // Activations and the residual are carried PRE-SCALED by kActScale (ReLU commutes with a positive
     // scale): res16 = 16 * x.  bias16/inv16 are prepared on the host.
     const int n_layers = 1 + a.n_res_layers;
+    uint32_t sat_bits = 0;
     uint4 wq_h[PB], wq_l[PB];  // weight-fragment ring of the conv that FOLLOWS the current epilogue
     for (int layer = 0; layer < n_layers; ++layer) {
         const bool last = layer == n_layers - 1;
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                     const float bb = e == 0 ? b4[g].x : (e == 1 ? b4[g].y : (e == 2 ? b4[g].z : b4[g].w));
                     float v = fmaf(acc[t][i], inv, bb);
                     if (add_res) v += res[t][i];
-                    v = __builtin_amdgcn_fmed3f(v, 0.f, 60000.f);  // ReLU + f16 range clamp (x <= 3750)
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, kActClamp);  // ReLU + f16 range clamp (x <= 3750)
+                    sat_bits = max(sat_bits, __float_as_uint(v));
                     if (set_res) res[t][i] = v;
                     acc[t][i] = 0.f;
                     vs[e] = v;
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     }
 
     // ---------------- heads (fp32 VALU): final activations (in `res`) -> LDS [256 cells][128] f32
+    if (sat_bits >= __float_as_uint(kActClamp)) atomicOr(a.sat, 1);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -352,7 +365,14 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
 // =================================================================================================
 using f32x4 = float __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
+#ifndef OTH_BUILTIN_MFMA
+    // accumulate IN PLACE (vDst = SrcC): the register allocator otherwise moves an accumulator to fresh registers at
+    // the head of a chain and pays WAR wait states (s_nop) when the freed registers are reused at once
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 // Chunk swizzle: within a ds_read_b128 lane group the two chunk indices differ in bit 0 and the cells split as
 // {(pos 0, x lo), (pos 1, x hi)} vs {(pos 0, x hi), (pos 1, x lo)} (x lo/hi = the two halves of the 8 shifted
@@ -468,8 +488,10 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
 
     const int n_layers = 1 + a.n_res_layers;
     uint4 wq[PB][4];  // weight ring [slot][rb0 hi, rb0 lo, rb1 hi, rb1 lo] of the conv that follows
+    uint32_t sat_bits = 0;   // largest activation seen (bit pattern): reaching the clamp sets the network's saturation flag
 #ifdef OTH_STAMPS
     unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, t0_ = oth_clk(), tstart_ = t0_;
+    const unsigned long long rstart_ = oth_realclk();
 #endif
     for (int layer = 0; layer < n_layers; ++layer) {
         const bool last = layer == n_layers - 1;
@@ -486,46 +508,70 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                 for (int f = 0; f < 4; ++f)
                     if (X3 || !(f & 1)) wq[i][f] = wl[(size_t)i * 1024 + f * 64];
         }
-        // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split
-        const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
-        const bool set_res = layer == 0 || add_res;
-        OTH_STAMP(0)
-        lds_barrier();  // every wave has finished reading the previous activations
-        OTH_STAMP(1)
+        // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split.  The three
+        // flags are compile-time (four instantiations of the same body): a run-time add_res / set_res costs two
+        // v_cndmask per value and a branch per store on `last` (a fifth of the epilogue's VALU work).
+        auto epilogue = [&](auto ADD, auto SET, auto LAST) {
+            constexpr bool add_res = decltype(ADD)::value;    // second conv of a block (net.py:58)
+            constexpr bool set_res = decltype(SET)::value;
+            constexpr bool is_last = decltype(LAST)::value;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                float vs[4];
+                for (int rb = 0; rb < 2; ++rb) {
+                    float vs[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float bb = e == 0 ? b4[rb].x : (e == 1 ? b4[rb].y : (e == 2 ? b4[rb].z : b4[rb].w));
-                    float v = fmaf(acc[t][rb][e], inv, bb);
-                    if (add_res) v += res[t][rb][e];
-                    v = __builtin_amdgcn_fmed3f(v, 0.f, 60000.f);  // ReLU + f16 range clamp (x <= 3750)
-                    if (set_res) res[t][rb][e] = v;
-                    acc[t][rb][e] = 0.f;
-                    vs[e] = v;
-                }
-                if (!last) {
-                    half4 hi;
+                    for (int e = 0; e < 4; ++e) {
+                        const float bb = e == 0 ? b4[rb].x : (e == 1 ? b4[rb].y : (e == 2 ? b4[rb].z : b4[rb].w));
+                        float v = fmaf(acc[t][rb][e], inv, bb);
+                        if (add_res) v += res[t][rb][e];
+                        v = __builtin_amdgcn_fmed3f(v, 0.f, kActClamp);  // ReLU + f16 range clamp (x <= 3750)
+                        if (set_res) res[t][rb][e] = v;
+                        acc[t][rb][e] = 0.f;
+                        vs[e] = v;
+                    }
+                    // saturation watch: non-negative floats order like their bit patterns (one v_max3_u32 per pair)
+                    sat_bits = max(sat_bits, max(__float_as_uint(vs[0]), __float_as_uint(vs[1])));
+                    sat_bits = max(sat_bits, max(__float_as_uint(vs[2]), __float_as_uint(vs[3])));
+                    if (!is_last) {
+                        half4 hi;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
-                    char* dst = lds + OTH_TILE_CELL(t) * kCellBytes + wr_off[rb];
-                    *(half4*)dst = hi;
-                    if (X3) {
-                        half4 lo;
+                        for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
+                        char* dst = lds + OTH_TILE_CELL(t) * kCellBytes + wr_off[rb];
+                        *(half4*)dst = hi;
+                        if (X3) {
+                            half4 lo;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(vs[e] - (float)hi[e]);
-                        *(half4*)(dst + 256) = lo;
+                            for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(vs[e] - (float)hi[e]);
+                            *(half4*)(dst + 256) = lo;
+                        }
                     }
                 }
             }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        OTH_STAMP(0)
+        lds_barrier();  // every wave has finished reading the previous activations
+        OTH_STAMP(1)
+        if (layer == 0) {
+            if (last) epilogue(F_{}, T_{}, T_{});
+            else epilogue(F_{}, T_{}, F_{});
+        } else if (last) {
+            epilogue(T_{}, T_{}, T_{});      // the last layer is the second conv of the last block
+        } else if (layer & 1) {
+            epilogue(F_{}, F_{}, F_{});
+        } else {
+            epilogue(T_{}, T_{}, F_{});
         }
         if (last) break;
         OTH_STAMP(2)
         lds_barrier();
         OTH_STAMP(3)
+#ifdef OTH_STAMPS
+        if (a.tl && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256) && layer < 21)
+            a.tl[(blockIdx.x ? 64 : 0) + layer * 2] = t0_;
+#endif
 
         // ---------------- conv `layer+1`: 3 row offsets (compile-time) x 3 column offsets x 4 k-steps x tiles
         auto tap_row = [&](auto DYC) {
@@ -552,6 +598,69 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     if (X3) xl[q] = *(const half8*)(OTH_SRC(q) + 256);
                 }
                 half8 wh[2], wlo[2];
+#ifndef OTH_CLUMPED
+                // Interleaved issue order (every statement pinned by sched_barrier): the address arithmetic and the two
+                // LDS reads of tile q+PD and, at a k-step boundary, the four weight loads of k-step +PB are placed BETWEEN
+                // the six MFMAs of tile q -- one per MFMA slot (an MFMA holds the issue port for 8 of its 16 cycles) --
+                // instead of in a clump between two tiles, where they leave the matrix pipe idle for a wave that has
+                // the SIMD to itself (a lone wave ran 22.6 cycles per MFMA with the clumped order).
+#define OTH_SB __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const bool pf = q + PD < NQ;
+                    const int psl = (q + PD) % (PD + 1);
+                    const bool neww = (q % NTV) == 0;
+                    const int wslot = (q / NTV) % PB;
+                    int nstep = tap * 4 + q / NTV + PB;
+                    nstep = nstep < 36 ? nstep : 35;
+                    if (neww) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            wh[rb] = __builtin_bit_cast(half8, wq[wslot][rb * 2]);
+                            if (X3) wlo[rb] = __builtin_bit_cast(half8, wq[wslot][rb * 2 + 1]);
+                        }
+                    }
+                    const int t = OTH_TILE_OF(q);
+                    const int sl = q % (PD + 1);
+                    OTH_SB;
+                    if constexpr (X3) {
+                        acc[t][0] = mfma32(wh[0], xl[sl], acc[t][0]);
+                        OTH_SB;
+                        const char* src = pf ? OTH_SRC(q + PD) : lds;
+                        OTH_SB;
+                        acc[t][0] = mfma32(wh[0], xh[sl], acc[t][0]);
+                        OTH_SB;
+                        if (neww) wq[wslot][0] = wl[(size_t)nstep * 1024];
+                        OTH_SB;
+                        acc[t][0] = mfma32(wlo[0], xh[sl], acc[t][0]);
+                        OTH_SB;
+                        if (pf) xh[psl] = *(const half8*)src;
+                        if (neww) wq[wslot][1] = wl[(size_t)nstep * 1024 + 64];
+                        OTH_SB;
+                        acc[t][1] = mfma32(wlo[1], xh[sl], acc[t][1]);
+                        OTH_SB;
+                        if (pf) xl[psl] = *(const half8*)(src + 256);
+                        if (neww) wq[wslot][2] = wl[(size_t)nstep * 1024 + 128];
+                        OTH_SB;
+                        acc[t][1] = mfma32(wh[1], xh[sl], acc[t][1]);
+                        OTH_SB;
+                        if (neww) wq[wslot][3] = wl[(size_t)nstep * 1024 + 192];
+                        OTH_SB;
+                        acc[t][1] = mfma32(wh[1], xl[sl], acc[t][1]);
+                    } else {
+                        if (pf) xh[psl] = *(const half8*)OTH_SRC(q + PD);
+                        if (neww) {
+                            wq[wslot][0] = wl[(size_t)nstep * 1024];
+                            wq[wslot][2] = wl[(size_t)nstep * 1024 + 128];
+                        }
+                        OTH_SB;
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) acc[t][rb] = mfma32(wh[rb], xh[sl], acc[t][rb]);
+                    }
+                    OTH_SB;
+                }
+#undef OTH_SB
+#else
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (q + PD < NQ) {
@@ -598,6 +707,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
 #undef OTH_SRC
 #undef OTH_ROW_OK
 #undef OTH_TILE_OF
@@ -607,15 +717,22 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
         tap_row(std::integral_constant<int, 0>{});
         tap_row(std::integral_constant<int, 1>{});
         OTH_STAMP(4)
+#ifdef OTH_STAMPS
+        if (a.tl && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256) && layer < 21)
+            a.tl[(blockIdx.x ? 64 : 0) + layer * 2 + 1] = t0_;
+#endif
     }
 #ifdef OTH_STAMPS
     if (a.dbg && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
         for (int i = 0; i < 5; ++i) o[i] = ph_[i];
         o[5] = oth_clk() - tstart_;
+        o[6] = oth_realclk() - rstart_;
+        o[7] = rstart_;
     }
 #endif
 
+    if (sat_bits >= __float_as_uint(kActClamp)) atomicOr(a.sat, 1);   // rare: surfaced by oth_net_saturated
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -761,7 +878,11 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     a.n_res_layers = 2 * net->mfma->blocks;
     a.heads = net->heads;
     a.dbg = nullptr;
+    a.tl = nullptr;
+    a.sat = net->d_sat;
 #ifdef OTH_STAMPS
+    OTH_HIP(hipMalloc(&a.tl, 128 * sizeof(unsigned long long)));
+    OTH_HIP(hipMemset(a.tl, 0, 128 * sizeof(unsigned long long)));
     const unsigned dbg_grid = (unsigned)((n + 1) / 2);
     OTH_HIP(hipMalloc(&a.dbg, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
     OTH_HIP(hipMemset(a.dbg, 0, (size_t)dbg_grid * 4 * 8 * sizeof(unsigned long long)));
@@ -808,13 +929,30 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
         OTH_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)dbg_grid * 4 * 8);
         OTH_HIP(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double s[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t w = 0; w < (size_t)dbg_grid * 4; ++w)
-            for (int i = 0; i < 6; ++i) s[i] += (double)h[w * 8 + i];
+        double s[7] = {0, 0, 0, 0, 0, 0, 0};
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (size_t w = 0; w < (size_t)dbg_grid * 4; ++w) {
+            for (int i = 0; i < 7; ++i) s[i] += (double)h[w * 8 + i];
+            if (h[w * 8 + 5] == 0) continue;   // workgroup beyond n_valid
+            if (h[w * 8 + 7] < r0) r0 = h[w * 8 + 7];
+            if (h[w * 8 + 7] + h[w * 8 + 6] > r1) r1 = h[w * 8 + 7] + h[w * 8 + 6];
+        }
         const double nw = (double)dbg_grid * 4;
+        fprintf(stderr, "[stamps] in-kernel clock %.3f GHz (cycles / 100 MHz ticks); first start -> last end %.3f ms\n",
+                s[5] / s[6] * 0.1, (double)(r1 - r0) * 1e-5);
         fprintf(stderr, "[stamps] per-wave cycles: prefetch %.0f | barrier1 %.0f | epilogue %.0f | barrier2 %.0f | conv %.0f | total %.0f\n",
                 s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw, s[4] / nw, s[5] / nw);
         (void)hipFree(a.dbg);
+        unsigned long long tl[128];
+        OTH_HIP(hipMemcpy(tl, a.tl, sizeof(tl), hipMemcpyDeviceToHost));
+        (void)hipFree(a.tl);
+        if (getenv("OTH_TIMELINE") && tl[0]) {
+            fprintf(stderr, "[timeline] layer: wg0 conv start,end | wg256 conv start,end (kilocycles from wg0's first conv)\n");
+            for (int l = 0; l < 20; ++l)
+                fprintf(stderr, "[timeline] %2d: %8.1f %8.1f | %8.1f %8.1f\n", l, (double)(long long)(tl[l * 2] - tl[0]) * 1e-3,
+                        (double)(long long)(tl[l * 2 + 1] - tl[0]) * 1e-3, (double)(long long)(tl[64 + l * 2] - tl[0]) * 1e-3,
+                        (double)(long long)(tl[64 + l * 2 + 1] - tl[0]) * 1e-3);
+        }
     }
 #endif
     return OTH_OK;

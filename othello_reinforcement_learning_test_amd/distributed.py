@@ -3,7 +3,7 @@
 Self-play games are independent units (no cross-game state, weights read-only while playing), so the
 path shards with no data-path collective: rank r plays its share of the episodes with its own RNG
 stream.  The only exchange is the end-of-iteration all-gather of the replay tuples
-``(state f32[n,3,8,8], pi f32[n,65], z f32[n])`` so that every (replicated) trainer feeds the same
+``(state f32[n,3,S,S], pi f32[n,S*S+1], z f32[n])`` (S = 8, or 6 for BASELINE configs[4]) so that every (replicated) trainer feeds the same
 ``ReplayBuffer`` -- the multi-GPU form of ``replay_buffer.add(training_data)``
 (/root/reference/src/train/trainer.py:185; the reference itself is single-process).
 
@@ -22,31 +22,75 @@ def shard_episodes(num_episodes, rank, world_size):
     return int((num_episodes - rank + world_size - 1) // world_size) if num_episodes > rank else 0
 
 
+_GATHER_BUFFERS = {}   # (device, dtype, row shape, world) -> [rows, padded input, gathered, compacted output]
+
+
+def _gather_buffers(dev, dtype, row, world, nmax, total):
+    """Persistent buffers of the exchange: after the first step a step allocates nothing.  Capacity grows by powers of
+    two; at 8 ranks x 100 k tuples the three arrays hold 8 x 100 k x (768 + 260 + 4) B = 0.83 GB gathered plus the
+    same compacted, 0.10 GB padded input -- 1.8 GB of the 288 GB, allocated once."""
+    import torch
+    key = (str(dev), dtype, tuple(row), world)
+    buf = _GATHER_BUFFERS.get(key)
+    if buf is None or buf[0] < nmax:
+        rows = 1024
+        while rows < nmax:
+            rows *= 2
+        buf = [rows, torch.zeros((rows,) + tuple(row), dtype=dtype, device=dev),
+               torch.empty((world * rows,) + tuple(row), dtype=dtype, device=dev),
+               torch.empty((world * rows,) + tuple(row), dtype=dtype, device=dev)]
+        _GATHER_BUFFERS[key] = buf
+    return buf
+
+
 def all_gather_replay(states, pis, zs, group=None, force=False):
-    """All-gather variable-length replay tuples.  Inputs are torch tensors on one device (CUDA for
-    RCCL, CPU for gloo) with a common leading length n_r.  Returns (states, pis, zs, counts) where the
-    arrays are the concatenation over ranks in rank order and counts[r] = n_r."""
+    """All-gather variable-length replay tuples.  Inputs are torch tensors (or lists of tensors, concatenated in
+    order) on one device (CUDA for RCCL, CPU for gloo) with a common leading length n_r.  Returns (states, pis, zs, counts) where the
+    arrays are the concatenation over ranks in rank order and counts[r] = n_r.
+
+    The returned arrays are VIEWS of persistent buffers (valid until the next call on this device): the padded input
+    and the gathered output are reused from step to step, equal counts return the gathered buffer itself, unequal
+    counts are compacted with world slice copies into a second persistent buffer -- no per-step allocation, no
+    torch.cat."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        if isinstance(zs, (list, tuple)):
+            states, pis, zs = (torch.cat(list(t)) for t in (states, pis, zs))
         return states, pis, zs, [int(zs.shape[0])]   # force=True runs the collectives on a one-rank group (RCCL smoke test)
     world = dist.get_world_size(group)
-    dev = zs.device
-    n = torch.tensor([zs.shape[0]], dtype=torch.int64, device=dev)
+    # each argument may also be a LIST of tensors (e.g. one per engine lane): the parts are written one after the other
+    # straight into the persistent padded buffer, so the caller needs no torch.cat of its own
+    states, pis, zs = ([t] if not isinstance(t, (list, tuple)) else list(t) for t in (states, pis, zs))
+    dev = zs[0].device
+    mine = sum(int(t.shape[0]) for t in zs)
+    n = torch.tensor([mine], dtype=torch.int64, device=dev)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, n, group=group)
     counts = counts.cpu().tolist()
-    nmax = max(counts)
+    nmax, total = max(counts), sum(counts)
     out = []
-    for t in (states, pis, zs):
-        t = t.contiguous()
-        row = t.shape[1:]
-        pad = torch.zeros((nmax,) + tuple(row), dtype=t.dtype, device=dev)
-        pad[: t.shape[0]] = t
-        gathered = torch.empty((world * nmax,) + tuple(row), dtype=t.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, pad, group=group)
-        gathered = gathered.view((world, nmax) + tuple(row))
-        out.append(torch.cat([gathered[r, : counts[r]] for r in range(world)], dim=0))
+    for parts in (states, pis, zs):
+        row = tuple(parts[0].shape[1:])
+        if nmax == 0:
+            out.append(parts[0][:0])
+            continue
+        _, pad, gathered, compact = _gather_buffers(dev, parts[0].dtype, row, world, nmax, total)
+        pad_v = pad[:nmax]
+        at = 0
+        for t in parts:
+            pad_v[at: at + t.shape[0]] = t
+            at += int(t.shape[0])
+        gath_v = gathered[: world * nmax]
+        dist.all_gather_into_tensor(gath_v, pad_v, group=group)
+        if all(c == nmax for c in counts):
+            out.append(gath_v)
+            continue
+        off = 0
+        for r in range(world):
+            compact[off: off + counts[r]] = gath_v[r * nmax: r * nmax + counts[r]]
+            off += counts[r]
+        out.append(compact[:total])
     return out[0], out[1], out[2], counts
 
 
@@ -66,6 +110,9 @@ class DistributedSelfPlayWorker:
     def execute_episodes_tensors(self, num_episodes, add_dirichlet_noise=True):
         """-> CUDA tensors (states, pis, zs) of the WHOLE job, plus per-rank tuple counts."""
         mine = shard_episodes(num_episodes, self.rank, self.world_size)
+        if getattr(self.worker, "_streaming", False):
+            raise RuntimeError("DistributedSelfPlayWorker needs a batch-mode worker (continuous=False): a batch run "
+                               "would drop the stream's in-flight games")
         if hasattr(self.worker, "_grow_engine"):
             self.worker._grow_engine(mine)   # auto slot width: the whole share at once (results do not depend on it)
         eng = self.worker.engine
@@ -77,8 +124,8 @@ class DistributedSelfPlayWorker:
             eng.selfplay_run(mine, seed, add_dirichlet_noise)
             st, pi, z = eng.selfplay_device_tensors()
         else:
-            st = torch.empty((0, 3, 8, 8), dtype=torch.float32, device="cuda")
-            pi = torch.empty((0, 65), dtype=torch.float32, device="cuda")
+            st = torch.empty((0, 3, eng.board_size, eng.board_size), dtype=torch.float32, device="cuda")   # 6x6: (0,3,6,6)
+            pi = torch.empty((0, eng.npol), dtype=torch.float32, device="cuda")
             z = torch.empty((0,), dtype=torch.float32, device="cuda")
         return all_gather_replay(st, pi, z, self.group)
 

@@ -86,6 +86,22 @@ class HipResNetEvaluator:
                   n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
         return logp, v.view(n, 1)
 
+    def saturated(self):
+        """True when an fp16-split trunk launch since the last call clamped an activation at 3750 (the reference's
+        fp32 forward has no clamp): reads and clears the device flag (one 4-byte copy, synchronises the stream)."""
+        flag = C.c_int32(0)
+        _lib.call("oth_net_saturated", self._h, C.byref(flag), _lib.current_stream())
+        return bool(flag.value)
+
+    def check_saturation(self):
+        """Loud failure instead of a silent deviation from the reference: called by the workers and the search mirrors
+        at the end of every call (they synchronise there anyway)."""
+        if self.precision != "f32" and self.saturated():
+            raise _lib.OthelloHipError(
+                "an activation of the %dx%d network exceeded 3750, the range of the fp16-split trunk kernel: results "
+                "would differ from the reference's fp32 forward -- build the evaluator with precision='f32'"
+                % (self.num_blocks, self.num_filters))
+
     def policy_probs(self, logp):
         """exp(log-probs) with the engine's own expf (what the expansion feeds node.py:71-80): CUDA tensor in/out."""
         import torch
@@ -101,6 +117,25 @@ class HipResNetEvaluator:
                 self._h = None
         except Exception:
             pass
+
+
+def policy_from_visits(visits, self_b, opp_b, temperature, board_size=8):
+    """MCTSNode.get_policy_distribution for a general temperature (/root/reference/src/mcts/node.py:162-182), the same
+    numpy expressions in the same order on the root's children (= the legal moves in ascending order, or the pass):
+    float32 counts ** (1.0 / T), /= counts.sum(), scatter.  Bit-identical to the reference by construction."""
+    npol = board_size * board_size + 1
+    policy = np.zeros(npol, dtype=np.float32)
+    legal = int(_lib.load().oth_legal_moves_n(board_size, self_b, opp_b))
+    actions = [a for a in range(npol - 1) if (legal >> a) & 1] or [npol - 1]
+    counts = np.array([visits[a] for a in actions], dtype=np.float32)
+    if temperature == 0:
+        policy[actions[int(np.argmax(counts))]] = 1.0
+    else:
+        counts = counts ** (1.0 / temperature)
+        counts /= counts.sum()
+        for a, p in zip(actions, counts):
+            policy[a] = p
+    return policy
 
 
 class SearchEngine:
@@ -136,6 +171,7 @@ class SearchEngine:
         s = np.ascontiguousarray(self_b, dtype=np.uint64)
         o = np.ascontiguousarray(opp_b, dtype=np.uint64)
         self._n = len(s)
+        self._roots = (s.copy(), o.copy())
         _lib.call("oth_search_begin", self._h, _lib.np_ptr(s, C.c_uint64), _lib.np_ptr(o, C.c_uint64),
                   self._n, _lib.current_stream())
 
@@ -162,6 +198,13 @@ class SearchEngine:
         _lib.call("oth_search_run", self._h, _lib.current_stream())
 
     def search_results(self, temperature=1.0):
+        """-> (pi, visits, value_sum, prior) of the roots.  temperature 0 / 1 come from the device (k_results); any
+        other value is node.py:175-177 evaluated literally on the host from the device's visit counts."""
+        if temperature not in (0, 0.0, 1, 1.0):
+            _, visits, wsum, prior = self.search_results(1.0)
+            pi = np.stack([policy_from_visits(visits[i], int(self._roots[0][i]), int(self._roots[1][i]), temperature,
+                                              self.board_size) for i in range(self._n)])
+            return pi, visits, wsum, prior
         n = self._n
         pi = np.zeros((n, self.npol), dtype=np.float32)
         visits = np.zeros((n, self.npol), dtype=np.int32)

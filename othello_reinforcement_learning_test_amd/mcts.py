@@ -59,12 +59,12 @@ class MCTS:
         eng = self._engine(num_simulations)
         eng.search_begin([board.self_board], [board.opp_board])
         eng.search_run()
-        return eng.search_results(temperature)
+        out = eng.search_results(temperature)
+        self.evaluator.check_saturation()
+        return out
 
     def search(self, board, num_simulations, temperature=1.0, add_dirichlet_noise=False):
         """-> (policy (65,) float32, root_value).  mcts.py:49-98."""
-        if temperature not in (0, 0.0, 1, 1.0):
-            raise ValueError("temperature must be 0 or 1 (the values the reference's workers use)")
         if add_dirichlet_noise:  # mcts.py:85-86 / :220-221: consumes the RNG, cannot alter the result
             n_legal = len(board.get_legal_moves())
             np.random.dirichlet([self.dirichlet_alpha] * n_legal)

@@ -53,8 +53,6 @@ class BatchMCTS:
         n = len(boards)
         if n == 0:
             return []
-        if temperature not in (0, 0.0, 1, 1.0):
-            raise ValueError("temperature must be 0 or 1")
         if not self._external:
             self.evaluator.refresh()
         if add_dirichlet_noise:  # :111-118: one draw per board, in board order
@@ -68,6 +66,7 @@ class BatchMCTS:
             eng.search_begin(sb, ob)
             eng.search_run()
             pi, _, _, _ = eng.search_results(float(temperature))
+            self.evaluator.check_saturation()
         return [(pi[i].copy(), 0.0) for i in range(n)]  # root value is always 0.0
 
 
@@ -133,6 +132,8 @@ class ParallelSelfPlayWorker:
         """Auto mode: make the single engine wide enough to play the whole call at once (power of two, <= 4096)."""
         if self.device_slots is not None:
             return
+        if self._streaming:   # in-flight games live in the current engine: never replace it under a stream
+            return
         want = self.num_parallel_games
         while want < min(int(num_episodes), 4096):
             want *= 2
@@ -183,18 +184,31 @@ class ParallelSelfPlayWorker:
         self._ran = [eng]
         if not self._streaming:
             self.stream_seed = int(np.random.randint(0, 2**62))
-            eng.stream_begin(self.stream_seed, stagger_rounds=self.stagger_rounds,
-                             hist_games=max(8 * eng.max_games, 2 * int(num_episodes) + 4 * eng.max_games))
+            self._hist_games = max(8 * eng.max_games, 2 * int(num_episodes) + 4 * eng.max_games)
+            eng.stream_begin(self.stream_seed, stagger_rounds=self.stagger_rounds, hist_games=self._hist_games)
+            self._hist_games = 1 << (self._hist_games - 1).bit_length()   # the engine rounds the ring up to a power of two
             self._streaming = True
-        g, n = eng.stream_step(int(num_episodes))
-        self.last_game_ids = eng.game_ids()
-        return eng.selfplay_fetch(n)[:3]
+        # the history ring was sized by the first call: a later, larger request is played in steps the ring can hold
+        cap = max(1, (self._hist_games - 2 * eng.max_games) // 2)
+        left, parts, ids = int(num_episodes), [], []
+        while left > 0:
+            g, n = eng.stream_step(min(left, cap))
+            ids.append(eng.game_ids())
+            parts.append(eng.selfplay_fetch(n)[:3])
+            left -= g
+        self.last_game_ids = np.concatenate(ids)
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(np.concatenate([p[j] for p in parts]) for j in range(3))
 
     # ---- numpy RNG: the reference's lock-step batches, draws in the reference's order --------
     def _execute_batch_numpy(self, batch_size, add_dirichlet_noise):
         """parallel_self_play.py:324-407 with the search, recording and moves on the device; the
         host only draws the random numbers (it mirrors the boards to know the legal-move counts)."""
         eng = self.engine
+        if eng.board_size != 8:   # the host mirror boards below are the reference's 8x8 OthelloBitboard
+            raise ValueError("rng_mode='numpy' replays the reference's 8x8 RNG order; use rng_mode='device' on a "
+                             "%dx%d board" % (eng.board_size, eng.board_size))
         boards = [self.board_class() for _ in range(batch_size)]
         for b in boards:
             b.reset()
@@ -211,7 +225,7 @@ class ParallelSelfPlayWorker:
             actions = np.zeros(batch_size, dtype=np.int32)
             for i in active:  # :375-397
                 if ply[i] < self.temperature_threshold:
-                    a = int(np.random.choice(65, p=pi[i]))
+                    a = int(np.random.choice(eng.npol, p=pi[i]))
                 else:
                     a = int(np.argmax(pi[i]))
                 actions[i] = a
@@ -243,26 +257,33 @@ class ParallelSelfPlayWorker:
                 states, pis, zs = self._execute_batch_numpy(bs, add_dirichlet_noise)
                 data.extend(tuples_from_arrays(states, pis, zs))
                 done += bs
+        self.batch_mcts.evaluator.check_saturation()   # loud failure if the fp16-split trunk clamped an activation
         dt = time.time() - t0
         counters = {}
         for eng in (self._ran if self.rng_mode == "device" else [self.engine]):
             for k, v in eng.counters().items():
                 counters[k] = counters.get(k, 0) + v
-        self.last_stats = {"games": num_episodes, "samples": len(data), "seconds": dt,
-                           "games_per_s": num_episodes / dt if dt > 0 else float("inf"), **counters}
+        games = len(self.last_game_ids) if (self.continuous and self.rng_mode == "device") else num_episodes
+        self.last_stats = {"games": games, "samples": len(data), "seconds": dt,
+                           "games_per_s": games / dt if dt > 0 else float("inf"), **counters}
         if self.verbose:
             print("  Self-Play: %d/%d games | %s samples | %.1fs (%.2f games/s)" %
-                  (num_episodes, num_episodes, format(len(data), ","), dt, self.last_stats["games_per_s"]))
+                  (games, num_episodes, format(len(data), ","), dt, self.last_stats["games_per_s"]))
         return data
 
     def execute_episodes_arrays(self, num_episodes, add_dirichlet_noise=True, seed=None):
         """Array form for callers that keep replay data on the device side: (states, pis, zs)."""
+        if self._streaming:
+            raise RuntimeError("this worker is streaming (continuous=True): a batch run would drop its in-flight "
+                               "games -- use execute_episodes")
         self.batch_mcts.evaluator.refresh()
         if seed is None:
             seed = int(np.random.randint(0, 2**62))
         self._grow_engine(num_episodes)
         n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
-        return self.engine.selfplay_fetch(n)[:3]
+        out = self.engine.selfplay_fetch(n)[:3]
+        self.batch_mcts.evaluator.check_saturation()
+        return out
 
 
 def create_parallel_self_play_worker(config, model, device=None, **kwargs):

@@ -19,19 +19,30 @@ import numpy as np
 from . import _lib
 
 
+def _board_size_of(states):
+    bs = int(states.shape[-1])
+    if states.dim() != 4 or states.shape[1] != 3 or states.shape[2] != bs or bs not in (6, 8):
+        raise ValueError("states must be (n, 3, S, S) with S = 8 or 6, got %s" % (tuple(states.shape),))
+    return bs
+
+
 def augment_symmetries(states, pis, zs):
-    """CUDA tensors (n,3,8,8), (n,65), (n,) -> (8n,3,8,8), (8n,65), (8n,): out[8*i + k] is symmetry k of
-    sample i, in ``get_symmetries`` order."""
+    """CUDA tensors (n,3,S,S), (n,S*S+1), (n,) -> (8n,3,S,S), (8n,S*S+1), (8n,) for S = 8 (the reference's board) or
+    6 (BASELINE configs[4]): out[8*i + k] is symmetry k of sample i, in ``get_symmetries`` order."""
     import torch
     _lib.require_device()
     states, pis, zs = states.contiguous(), pis.contiguous(), zs.contiguous()
     if not (states.is_cuda and pis.is_cuda and zs.is_cuda):
         raise ValueError("augment_symmetries expects CUDA tensors")
+    bs = _board_size_of(states)
+    npol = bs * bs + 1
     n = int(zs.shape[0])
-    so = torch.empty((8 * n, 3, 8, 8), dtype=torch.float32, device=states.device)
-    po = torch.empty((8 * n, 65), dtype=torch.float32, device=states.device)
+    if tuple(pis.shape) != (n, npol) or states.shape[0] != n:
+        raise ValueError("pis must be (%d, %d) for a %dx%d board, got %s" % (n, npol, bs, bs, tuple(pis.shape)))
+    so = torch.empty((8 * n, 3, bs, bs), dtype=torch.float32, device=states.device)
+    po = torch.empty((8 * n, npol), dtype=torch.float32, device=states.device)
     zo = torch.empty((8 * n,), dtype=torch.float32, device=states.device)
-    _lib.call("oth_augment_symmetries", states.data_ptr(), pis.data_ptr(), zs.data_ptr(), n,
+    _lib.call("oth_augment_symmetries_n", bs, states.data_ptr(), pis.data_ptr(), zs.data_ptr(), n,
               so.data_ptr(), po.data_ptr(), zo.data_ptr(), _lib.current_stream())
     return so, po, zo
 
@@ -58,12 +69,17 @@ class DeviceReplayBuffer:
     than ``batch_size`` items (buffer.py:72-75).
     """
 
-    def __init__(self, max_size=100000, device="cuda"):
+    def __init__(self, max_size=100000, device="cuda", board_size=8):
         import torch
+        if board_size not in (6, 8):
+            raise ValueError("board_size must be 8 or 6")
         self.max_size = int(max_size)
         self.device = torch.device(device)
-        self.states = torch.zeros((self.max_size, 3, 8, 8), dtype=torch.float32, device=self.device)
-        self.policies = torch.zeros((self.max_size, 65), dtype=torch.float32, device=self.device)
+        self.board_size = int(board_size)      # 8: the reference's game; 6: BASELINE configs[4] tuples (n,3,6,6)/(n,37)
+        self.npol = self.board_size * self.board_size + 1
+        self.states = torch.zeros((self.max_size, 3, self.board_size, self.board_size), dtype=torch.float32,
+                                  device=self.device)
+        self.policies = torch.zeros((self.max_size, self.npol), dtype=torch.float32, device=self.device)
         self.values = torch.zeros((self.max_size,), dtype=torch.float32, device=self.device)
         self._head = 0      # next write position
         self._size = 0
@@ -91,10 +107,14 @@ class DeviceReplayBuffer:
             z = torch.tensor([float(d[2]) for d in training_data], dtype=torch.float32)
         else:
             st, pi, z = training_data
-        st = st.to(self.device, torch.float32).reshape(-1, 3, 8, 8)
-        pi = pi.to(self.device, torch.float32).reshape(-1, 65)
         z = z.to(self.device, torch.float32).reshape(-1)
         n = int(z.shape[0])
+        bs = self.board_size
+        if st.numel() != n * 3 * bs * bs or pi.numel() != n * self.npol:   # never reinterpret another board's rows
+            raise ValueError("tuples of %d samples do not have the (3,%d,%d) / (%d,) shapes of this buffer: %s, %s"
+                             % (n, bs, bs, self.npol, tuple(st.shape), tuple(pi.shape)))
+        st = st.to(self.device, torch.float32).reshape(n, 3, bs, bs)
+        pi = pi.to(self.device, torch.float32).reshape(n, self.npol)
         if n >= self.max_size:  # only the newest max_size items survive, oldest first
             st, pi, z = st[n - self.max_size:], pi[n - self.max_size:], z[n - self.max_size:]
             self.states.copy_(st); self.policies.copy_(pi); self.values.copy_(z)
@@ -113,7 +133,7 @@ class DeviceReplayBuffer:
         return (start + k) % self.max_size
 
     def sample(self, batch_size):
-        """-> (states (B,3,8,8), policies (B,65), values (B,1)) tensors on the buffer's device."""
+        """-> (states (B,3,S,S), policies (B,S*S+1), values (B,1)) tensors on the buffer's device."""
         import torch
         if self._size < batch_size:   # buffer.py:72-75
             raise ValueError(f"Buffer size ({self._size}) is smaller than batch size ({batch_size})")
@@ -121,11 +141,11 @@ class DeviceReplayBuffer:
         if self.device.type != "cuda":   # CPU tensors (the host-side tests): plain indexing
             idx = self._logical_index(pick)
             return self.states[idx], self.policies[idx], self.values[idx].reshape(-1, 1)
-        st = torch.empty((batch_size, 3, 8, 8), dtype=torch.float32, device=self.device)
-        pi = torch.empty((batch_size, 65), dtype=torch.float32, device=self.device)
+        st = torch.empty((batch_size, 3, self.board_size, self.board_size), dtype=torch.float32, device=self.device)
+        pi = torch.empty((batch_size, self.npol), dtype=torch.float32, device=self.device)
         v = torch.empty((batch_size,), dtype=torch.float32, device=self.device)
         start = (self._head - self._size) % self.max_size
-        _lib.call("oth_replay_gather", self.states.data_ptr(), self.policies.data_ptr(), self.values.data_ptr(),
+        _lib.call("oth_replay_gather_n", self.board_size, self.states.data_ptr(), self.policies.data_ptr(), self.values.data_ptr(),
                   pick.data_ptr(), int(batch_size), int(start), int(self.max_size), st.data_ptr(), pi.data_ptr(),
                   v.data_ptr(), _lib.current_stream())
         return st, pi, v.reshape(-1, 1)

@@ -12,10 +12,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Multi-rank rehearsal of bench.py's N>1 path (tests/test_gpu_multirank.py): two ranks sharing GPU 0 over gloo.
+# Multi-rank rehearsal of bench.py's N>1 path (tests/test_gpu_multirank.py): FOUR ranks sharing GPU 0 over gloo (the
+# GPU box admits at most 6 processes on its card: 4 ranks + this pytest process; the world-size-8 form of the exchange
+# step runs on CPU tensors in tests/test_distributed_cpu.py).
 # The children must be started BEFORE this process touches the GPU (a GPU-initialised process must not fork+exec on
 # this pool), so they are launched here, at session start of a `-m gpu` run, and the test only collects the result.
 REHEARSAL = {"proc": None, "out": None, "err": None}
+REHEARSAL_RANKS = 4
 
 
 def _wants_gpu(config):
@@ -30,6 +33,11 @@ def pytest_configure(config):
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-s", "-j4", "-C",
                                os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "csrc")])
+    # the CPU oracle (both board sizes), (re)built here -- before anything touches the GPU -- and never from lib()
+    import oracle_lib
+    import oracle_lib6
+    oracle_lib.build()
+    oracle_lib6.build()
 
 
 def pytest_sessionstart(session):
@@ -44,9 +52,11 @@ def pytest_sessionstart(session):
     sock.close()
     env = dict(os.environ)
     env.update({"OTHELLO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    REHEARSAL["ranks"] = REHEARSAL_RANKS
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(REHEARSAL_RANKS),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "64", "--step-games", "32", "--sims", "6",
+           "--gpus", str(REHEARSAL_RANKS), "--steps", "2", "--warmup", "1", "--games", "64", "--step-games", "32",
+           "--sims", "6",
            "--blocks", "2", "--filters", "16", "--stagger", "8", "--profile-steps", "1", "--no-cpu-baseline"]
     REHEARSAL["proc"] = subprocess.Popen(cmd, stdout=out, stderr=err, env=env, cwd=ROOT)
     REHEARSAL["out"], REHEARSAL["err"] = out.name, err.name

@@ -17,6 +17,9 @@ are stored (fixtures G1..G5).  Files are small (each wel
   g5_episodes.npz  SelfPlayWorker and ParallelSelfPlayWorker episode streams (2x16 net, 5 sims,
                    seeds 42/43): states, pi, z, actions, and the numpy RNG draws they consumed
   g6_arena.npz     src/eval Arena results (greedy/random players, seeded) and GreedyPlayer choices
+  g8_extra.npz     OthelloBitboard.get_symmetries of 120 positions with random pi (8 boards + 8 policies each), and
+                   MCTS.search at temperatures 0.5 and 2.0 (node.py:175-177's counts ** (1/T)) under the stub evaluator
+                   (--only-g8 writes just this file; g7 is tests/golden/make_golden_net6.py)
 """
 import hashlib
 import os
@@ -462,16 +465,64 @@ def gen_arena():
     print("g6: arena results and %d greedy choices" % len(act))
 
 
+def gen_extra():
+    """g8: symmetries (bitboard.pyx:338-370) and general-temperature policies (node.py:162-182)."""
+    g1 = np.load(os.path.join(HERE, "g1_rules.npz"))
+    rng = np.random.Generator(np.random.PCG64(88))
+    pos = g1["game_pos"]
+    idx = rng.choice(len(pos), 120, replace=False)
+    sym_pos, sym_pi, sym_states, sym_pis = [], [], [], []
+    for i in idx:
+        s, o = int(pos[i, 0]), int(pos[i, 1])
+        pi = rng.dirichlet([0.3] * 65).astype(np.float32)
+        out = board_from(s, o).get_symmetries(pi)
+        assert len(out) == 8
+        sym_pos.append((s, o)); sym_pi.append(pi)
+        sym_states.append(np.stack([np.asarray(b, dtype=np.float32) for b, _ in out]))
+        sym_pis.append(np.stack([np.asarray(p, dtype=np.float32) for _, p in out]))
+    stub = StubModel()
+    dev = torch.device("cpu")
+    cases, pol = [], []
+    for i in rng.choice(len(pos), 40, replace=False):
+        s, o = int(pos[i, 0]), int(pos[i, 1])
+        b = board_from(s, o)
+        if b.is_terminal():
+            continue
+        for temp in (0.5, 2.0):
+            for sims in (25, 50):
+                m = MCTS(stub, dev, c_puct=1.0)
+                pi, rv = m.search(board_from(s, o), sims, temperature=temp, add_dirichlet_noise=False)
+                assert rv == 0.0 and pi.dtype == np.float32
+                cases.append((s, o, sims, int(temp * 1000)))
+                pol.append(pi)
+    g3_exp = np.load(os.path.join(HERE, "g3_search.npz"))["stub_exp"]   # the checker uses g3's table of torch.exp
+    for k, v in stub.exp_seen.items():
+        assert np.float32(v) == g3_exp[k]
+    np.savez_compressed(
+        os.path.join(HERE, "g8_extra.npz"),
+        sym_pos=np.array(sym_pos, dtype=U64), sym_pi=np.array(sym_pi, dtype=np.float32),
+        sym_states=np.array(sym_states, dtype=np.float32), sym_pis=np.array(sym_pis, dtype=np.float32),
+        temp_pos=np.array([[c[0], c[1]] for c in cases], dtype=U64),
+        temp_cfg=np.array([[c[2], c[3]] for c in cases], dtype=np.int32),
+        temp_policy=np.array(pol, dtype=np.float32), stub_logits=STUB_LOGITS,
+    )
+    print("g8: %d symmetry cases, %d temperature cases" % (len(sym_pos), len(cases)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if "--only-arena" in sys.argv:
         gen_arena()
+        sys.exit(0)
+    if "--only-g8" in sys.argv:
+        gen_extra()
         sys.exit(0)
     rows = gen_rules()
     gen_search(rows)
     gen_net(rows)
     gen_episodes()
     gen_arena()
+    gen_extra()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-18s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -21,6 +21,9 @@ _SO = os.path.join(ORACLE_DIR, _SO_NAME)
 
 
 def build():
+    """(Re)build the oracle with make when it is missing or older than its source.  This SPAWNS A PROCESS: call it only
+    before the calling process has initialised the GPU (tests/conftest.py::pytest_configure, __graft_entry__.build(),
+    the top of bench.main()); lib() below never builds."""
     src = os.path.join(ORACLE_DIR, "othello_oracle.c")
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, _SO_NAME])
@@ -61,7 +64,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        if not os.path.exists(_SO):   # never fork+exec make from here: the caller may already hold the GPU
+            raise RuntimeError("%s is not built: run __graft_entry__.build() (or pytest, whose conftest builds it)" % _SO)
+        L = C.CDLL(_SO)
         u64p, f32p, i32p, f64p = (C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_double))
         L.orc_flip_bits.restype = C.c_uint64

@@ -103,3 +103,56 @@ def test_bench_proportional_shares():
             s2 = bench.proportional_shares(rates2, nom, ln)
             assert sum(s2) == nom * len(rates2) and all(x % ln == 0 for x in s2)
             assert min(s2) >= 0.9 * nom - ln and max(s2) <= 1.1 * nom + ln, (rates2, nom, s2)
+
+
+def _worker_steps(rank, world, port, q):
+    """bench.py's exchange step at world size `world` on CPU tensors: several steps through the SAME persistent
+    buffers (growing, shrinking, equal and empty counts; two lane parts per rank), then the rate all-gather +
+    proportional_shares every rank must evaluate identically."""
+    import importlib.util
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        ok = True
+        plans = [[40 + 3 * r for r in range(world)], [7] * world, [0 if r % 3 == 0 else 90 - r for r in range(world)],
+                 [1500 if r == world - 1 else 2 for r in range(world)], [0] * world, [33] * world]
+        for step, counts in enumerate(plans):
+            st, pi, z = _make(100 * step + rank, counts[rank])
+            cut = counts[rank] // 3   # two "lanes"
+            gs, gp, gz, got = all_gather_replay([st[:cut], st[cut:]], [pi[:cut], pi[cut:]], [z[:cut], z[cut:]])
+            exp = [_make(100 * step + r, counts[r]) for r in range(world)]
+            ok &= got == counts and int(gz.shape[0]) == sum(counts)
+            ok &= torch.equal(gs, torch.cat([e[0] for e in exp])) and torch.equal(gp, torch.cat([e[1] for e in exp]))
+            ok &= torch.equal(gz, torch.cat([e[2] for e in exp]))
+        rate = torch.tensor([500.0 + 7.0 * rank], dtype=torch.float64)
+        allr = torch.zeros(world, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, rate)
+        shares = bench.proportional_shares(allr.numpy(), 1536, 2)
+        q.put((rank, bool(ok), shares))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_step_world8_gloo():
+    """The N = 8 form of BASELINE configs[2]'s exchange (counts, three padded all-gathers through persistent buffers,
+    rate all-gather, shares) by eight gloo ranks on CPU tensors -- the GPU box admits only six processes on its card,
+    so this is where world size 8 is exercised."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_steps, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    shares = [s for _, _, s in res]
+    assert all(s == shares[0] for s in shares) and sum(shares[0]) == 8 * 1536   # identical on every rank, total fixed

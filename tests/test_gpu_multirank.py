@@ -1,6 +1,7 @@
 """BASELINE.json configs[2] (N-GPU data-parallel self-play with an all-gather of the replay tuples) kept from
-rotting while no multi-GPU node is available: bench.py's N>1 path run by TWO ranks sharing GPU 0, collectives over
-gloo (RCCL needs one GPU per rank).  The ranks are started by tests/conftest.py at session start, before this
+rotting while no multi-GPU node is available: bench.py's N>1 path run by FOUR ranks sharing GPU 0, collectives over
+gloo (RCCL needs one GPU per rank; the box admits six processes on its card, so eight ranks cannot share it -- the
+world-size-8 exchange step runs on CPU tensors in tests/test_distributed_cpu.py).  The ranks are started by tests/conftest.py at session start, before this
 process initialises the GPU; this test waits for them and checks the JSON line."""
 import json
 
@@ -9,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_rehearsal(rehearsal):
+def test_bench_multi_rank_rehearsal(rehearsal):
     p = rehearsal["proc"]
     assert p is not None, "the rehearsal was not started (run with `-m gpu`)"
     rc = p.wait(timeout=900)
@@ -18,12 +19,14 @@ def test_bench_two_ranks_rehearsal(rehearsal):
     lines = [ln for ln in open(rehearsal["out"]).read().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 must print exactly one JSON line, got %d" % len(lines)
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    w = rehearsal["ranks"]
+    assert d["n_gpus"] == w and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "games/s" and d["value"] > 0 and d["higher_is_better"] is True
     cfg = d["config"]
-    assert cfg["games_timed"] >= 2 * 2 * 32           # both ranks' games are counted (whole-job aggregate)
-    assert "dp2" in cfg["parallelism"] and "all-gather" in cfg["parallelism"]
-    # the all-gathered tuple count of the last step covers both ranks: ~60 plies per game, >= 2 x 32 games
-    assert cfg["samples_last_step"] > 2 * 32 * 40
+    assert cfg["games_timed"] >= 2 * w * 29           # every rank's games are counted (shares within +-10 % of 32)
+    assert "dp%d" % w in cfg["parallelism"] and "all-gather" in cfg["parallelism"]
+    assert "REHEARSAL" in cfg["parallelism"] and "gloo" in cfg["parallelism"]    # never reads as an RCCL measurement
+    # the all-gathered tuple count of the last step covers all ranks: ~60 plies per game, ~32 games per rank
+    assert cfg["samples_last_step"] > w * 29 * 40
     assert d["roofline"]["launches"] > 0 and d["cpu_baseline"] is None
     assert "step 2/2" in err                            # heartbeat lines on stderr

@@ -140,6 +140,36 @@ def test_search_golden_cases(pkg, g3):
                 assert eng.counters()["simulations"] == len(sel) * int(sims)
 
 
+def test_search_general_temperature_vs_reference(pkg, g3, golden):
+    """MCTS.search / get_action_probs with temperature 0.5 and 2.0 (node.py:175-177: counts ** (1/T), renormalised in
+    float32) == the reference's own answers (g8, generated by the reference under the stub evaluator), through both
+    SearchEngine.search_with and BatchMCTS.search_batch; the round-2 ValueError for T not in {0, 1} is gone."""
+    g8 = golden("g8_extra.npz")
+    table = g3["stub_exp"]
+    fn = lambda s, o, lg: stub_probs_values(s, o, table)   # noqa: E731
+    cfg = g8["temp_cfg"]
+    for sims in sorted(set(cfg[:, 0])):
+        for t1000 in sorted(set(cfg[:, 1])):
+            sel = np.nonzero((cfg[:, 0] == sims) & (cfg[:, 1] == t1000))[0]
+            eng = pkg.SearchEngine(len(sel), int(sims), c_puct=1.0)
+            pos = g8["temp_pos"][sel]
+            pi, _, _, _ = eng.search_with(pos[:, 0], pos[:, 1], fn, t1000 / 1000.0)
+            assert np.array_equal(pi, g8["temp_policy"][sel]), (sims, t1000)
+
+    class Stub:
+        def host_eval(self, s, o, lg):
+            return stub_probs_values(s, o, table)
+    bm = pkg.BatchMCTS(None, evaluator=Stub(), c_puct=1.0)
+    sel = np.nonzero((cfg[:, 0] == 25) & (cfg[:, 1] == 500))[0][:9]
+    boards = []
+    for s, o in g8["temp_pos"][sel]:
+        b = pkg.OthelloBitboard()
+        b.self_board, b.opp_board = int(s), int(o)
+        boards.append(b)
+    res = bm.search_batch(boards, 25, temperature=0.5)
+    assert np.array_equal(np.stack([p for p, _ in res]), g8["temp_policy"][sel])
+
+
 def test_search_vs_oracle_many_positions(pkg, g3):
     """Fresh seeded positions, including late-game ones with terminal leaves and forced passes."""
     table = g3["stub_exp"]
@@ -387,6 +417,44 @@ def test_trunk_kernel_variants_agree(pkg):
                 os.environ[k] = val
     for x in outs[1:]:
         assert (x - outs[0]).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("blocks,filters,board", [(2, 128, 8), (2, 64, 8), (2, 32, 6)])
+def test_trunk_saturation_is_surfaced(pkg, blocks, filters, board):
+    """The fp16-split trunk kernels clamp activations at 3750; the reference's fp32 forward does not.  A network whose
+    activations go past the clamp must be REPORTED (oth_net_saturated -> OthelloHipError from the workers), never
+    silently different; the same weights under precision='f32' stay within tolerance of torch; an ordinary network
+    never raises the flag."""
+    torch.manual_seed(9)
+    net = pkg.OthelloResNet(blocks, filters, board_size=board).eval()
+    n = 130
+    x = (torch.rand(n, 3, board, board, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    ev = pkg.HipResNetEvaluator(net)
+    assert ev.precision == "f16x3"
+    ev.forward_planes(x)
+    assert not ev.saturated()
+    ev.check_saturation()
+    with torch.no_grad():
+        net.conv_block.bn.weight.mul_(30000.0)          # stem output (and everything after it) far beyond 3750
+    ev.refresh()
+    ev.forward_planes(x)
+    torch.cuda.synchronize()
+    assert ev.saturated() and not ev.saturated()         # reported once, then cleared
+    ev.forward_planes(x)
+    with pytest.raises(pkg._lib.OthelloHipError):
+        ev.check_saturation()
+    if filters != 128:   # the worker-level check (small network: a whole call takes a moment)
+        w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=2, num_parallel_games=4, verbose=False)
+        with pytest.raises(pkg._lib.OthelloHipError):
+            w.execute_episodes(2)
+    ev32 = pkg.HipResNetEvaluator(net, precision="f32")
+    logp, v = ev32.forward_planes(x)
+    with torch.no_grad():
+        rl, rv = net.cuda()(x)
+    net.cpu()
+    assert not ev32.saturated()
+    # activations of ~1e5 here: fp32 rounding scales with them, so the check is relative (and the tanh is saturated)
+    assert (logp - rl).abs().max().item() < 1e-4 * max(1.0, rl.abs().max().item()) and (v - rv).abs().max().item() < 2e-3
 
 
 def test_trunk_on_trained_like_weights(pkg):

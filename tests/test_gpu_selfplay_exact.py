@@ -63,32 +63,37 @@ def assert_streams_equal(got, want, what=""):
 
 
 CASES = [
-    # blocks, filters, sims, threshold, slots, games, late_onehot
-    pytest.param(2, 16, 6, 8, 16, 40, False, id="2x16-6sims-40games-16slots-refill"),
-    pytest.param(2, 16, 6, 8, 16, 40, True, id="2x16-late-onehot"),
-    pytest.param(2, 32, 12, 4, 8, 20, False, id="2x32-12sims"),
-    pytest.param(10, 128, 50, 15, 32, 64, False, id="10x128-50sims-64games-32slots"),
-    pytest.param(10, 128, 20, 15, 512, 600, False, id="10x128-20sims-600games-512slots-pair-kernel"),
+    # blocks, filters, sims, threshold, slots, games, late_onehot, c_puct
+    pytest.param(2, 16, 6, 8, 16, 40, False, 1.0, id="2x16-6sims-40games-16slots-refill"),
+    pytest.param(2, 16, 6, 8, 16, 40, True, 1.0, id="2x16-late-onehot"),
+    pytest.param(2, 32, 12, 4, 8, 20, False, 1.0, id="2x32-12sims"),
+    pytest.param(10, 128, 50, 15, 32, 64, False, 1.0, id="10x128-50sims-64games-32slots"),
+    pytest.param(10, 128, 20, 15, 512, 600, False, 1.0, id="10x128-20sims-600games-512slots-pair-kernel"),
+    # BASELINE.json configs[3] (strong play: 400 sims/move, c_puct 1.5, temperature threshold 20) end to end:
+    # 401-node trees per ply, 8 games through 8 slots on the 10x128 network
+    pytest.param(10, 128, 400, 20, 8, 8, False, 1.5, id="configs3-10x128-400sims-cpuct1.5-thr20-8games"),
     # BASELINE.json configs[1] at FULL size: 4096 concurrent games, 50 sims, 10x128 -- 248k tuples, 11.8 M network
     # evaluations, every one of them compared (about 50 s: 9 s of device play, the rest is the oracle's replay)
-    pytest.param(10, 128, 50, 15, 4096, 4096, False, id="FULL-SIZE-10x128-50sims-4096games-4096slots"),
+    pytest.param(10, 128, 50, 15, 4096, 4096, False, 1.0, id="FULL-SIZE-10x128-50sims-4096games-4096slots"),
 ]
 
 
-@pytest.mark.parametrize("blocks,filters,sims,thr,slots,games,onehot", CASES)
-def test_selfplay_device_rng_exact(pkg, blocks, filters, sims, thr, slots, games, onehot):
+@pytest.mark.parametrize("blocks,filters,sims,thr,slots,games,onehot,c_puct", CASES)
+def test_selfplay_device_rng_exact(pkg, blocks, filters, sims, thr, slots, games, onehot, c_puct):
     """oth_selfplay_run (Philox sampling, cumsum/searchsorted choice, arg-max after the threshold, slot refill,
     z sign, compaction order) == the oracle, tuple for tuple."""
     torch.manual_seed(100 + blocks)
     net = pkg.OthelloResNet(blocks, filters).eval()
     ev = pkg.HipResNetEvaluator(net)
-    eng = pkg.SearchEngine(slots, sims, temperature_threshold=thr, c_puct=1.0, store_late_onehot=onehot, evaluator=ev)
+    eng = pkg.SearchEngine(slots, sims, temperature_threshold=thr, c_puct=c_puct, store_late_onehot=onehot,
+                           evaluator=ev)
     seed = 0x1234ABCD5678 + games
     n = eng.selfplay_run(games, seed)
     st, pi, z, gl = eng.selfplay_fetch(n)
     assert np.array_equal(eng.game_ids(), np.arange(games))
     cb = hip_net_eval(ev, slots)
-    ws, wp, wz, wm, wl = ol.selfplay_philox(games, seed, sims, thr, cb, parallel_games=slots, late_onehot=onehot)
+    ws, wp, wz, wm, wl = ol.selfplay_philox(games, seed, sims, thr, cb, parallel_games=slots, c_puct=c_puct,
+                                            late_onehot=onehot)
     assert_streams_equal((st, pi, z, gl), (ws, wp, wz, wl))
     c = eng.counters()
     assert c["games"] == games and c["plies"] == len(z) and c["simulations"] == sims * len(z)
@@ -232,7 +237,8 @@ def test_episode_stream_numpy_rng_exact(pkg, golden, kind, seed, capsys):
     """rng_mode='numpy' (the reference's global-RNG draws in the reference's order): the worker's whole
     (state, pi, z) stream equals the oracle's when the oracle's evaluator is the HIP network itself -- no
     tolerance.  Against the reference-generated golden stream (torch CPU forward) the same run can differ after a
-    PUCT near-tie flips on the last float bits of the network; the matched prefix is printed, not asserted."""
+    PUCT near-tie flips on the last float bits of the network: the matched prefix is printed and must cover at
+    least 95 % of the golden stream (observed: 100 % in all four runs, z equal)."""
     g = golden("g5_episodes.npz")
     net = _load_g5_net(pkg, g, seed)
     np.random.seed(seed)
@@ -262,6 +268,9 @@ def test_episode_stream_numpy_rng_exact(pkg, golden, kind, seed, capsys):
         print("\n[g5 %s] golden-matched prefix: %d of %d samples (%.1f %%)%s"
               % (tag, first_bad, len(gs), 100.0 * first_bad / len(gs),
                  "" if first_bad < len(gs) else ", z equal: %s" % np.array_equal(z, gz)))
+    assert first_bad >= 0.95 * len(gs), "golden-matched prefix dropped to %d of %d" % (first_bad, len(gs))
+    if first_bad == len(gs) and len(st) == len(gs):
+        assert np.array_equal(z, gz)
 
 
 def test_batch_mcts_search_batch_vs_reference(pkg, golden):

@@ -129,3 +129,30 @@ def test_checkpoint_loader_roundtrip(tmp_path):
         with torch.no_grad():
             out = m(x)
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+
+
+def test_buffer_carries_6x6_tuples():
+    """BASELINE configs[4] tuples -- (3,6,6) states and 37-wide policies -- through the ring (CPU tensors): shapes kept,
+    FIFO order kept, and a mismatched board size is an error instead of a silent reinterpretation (108*n floats can be
+    divisible by 192)."""
+    import torch
+    from othello_reinforcement_learning_test_amd.replay import DeviceReplayBuffer
+    rng = np.random.Generator(np.random.PCG64(3))
+    buf = DeviceReplayBuffer(max_size=40, device="cpu", board_size=6)
+    data = [(rng.random((3, 6, 6)).astype(np.float32), rng.random(37).astype(np.float32), float(rng.integers(-1, 2)))
+            for _ in range(64)]
+    buf.add(data[:30])
+    buf.add(data[30:])
+    st, pi, z = buf.ordered()
+    assert tuple(st.shape) == (40, 3, 6, 6) and tuple(pi.shape) == (40, 37)
+    assert np.array_equal(st.numpy(), np.stack([d[0] for d in data[24:]]))
+    assert np.array_equal(pi.numpy(), np.stack([d[1] for d in data[24:]]))
+    s, p, v = buf.sample(16)
+    assert tuple(s.shape) == (16, 3, 6, 6) and tuple(p.shape) == (16, 37) and tuple(v.shape) == (16, 1)
+    buf8 = DeviceReplayBuffer(max_size=64, device="cpu")
+    with pytest.raises(ValueError):
+        buf8.add(data[:16])           # 16 x 108 floats == 9 x 192: must not be accepted as nine 8x8 states
+    with pytest.raises(ValueError):
+        buf.add((torch.zeros(4, 3, 8, 8), torch.zeros(4, 65), torch.zeros(4)))
+    with pytest.raises(ValueError):
+        DeviceReplayBuffer(max_size=8, device="cpu", board_size=7)

@@ -138,4 +138,5 @@ def main():
         print("activation max %.1f" % h64.abs().max())
 
 
-main()
+if __name__ == "__main__":
+    main()
