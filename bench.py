@@ -38,7 +38,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL
 
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0           # HBM3E peak, MI355X_MICROARCH.md
 PLIES_PER_GAME = 60.7           # measured by the engine over >100k games of this workload
+# Algorithmic bytes the tree kernel (k_tree, one launch per simulation) moves per game and simulation:
+# 24 B leaf position out + 264 B network result in (65 log-probs + value) + ~3 nodes of the descent x (32 B node + 8 edges
+# x 16 B) read + the ~3 path edges rewritten by the backup (16 B each) = 816 B.
+TREE_BYTES_PER_GAME_SIM = 24 + 264 + 3 * (32 + 8 * 16) + 3 * 16
 # Planning figure for the time budget only (tests/test_bench_budget.py): games/s one MI355X sustains on the default
 # workload, taken well below the slowest box measured (503-528 in round 1).
 PLANNING_RATE = 420.0
@@ -379,15 +384,19 @@ def main():
              % (prof["games"], prof["wall_s"], prof["net_launches"], prof["union_ms"]))
 
     if rank == 0:
-        traffic, traffic_file = None, None   # HBM-side bytes per k_trunk launch from the committed PMC profile (4096 positions)
-        for name in ("r02_trunk_traffic.json", "r01_trunk_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic = json.load(f)["traffic_bytes_per_launch"]
-                traffic_file = name
-                break
-            except Exception:
-                pass
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes over THIS command's own launch shape
+        # (two lanes, ~1 900 positions per trunk launch): profiles/r03_bench_traffic.json, written by tools/bench_pmc.sh
+        traffic, tree_traffic, traffic_basis = None, None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_bench_traffic.json")) as f:
+                tj = json.load(f)
+            traffic = tj["kernels"]["k_trunk16"]["traffic_bytes_per_launch"]
+            tree_traffic = tj["kernels"]["k_tree"]["traffic_bytes_per_launch"]
+            traffic_basis = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `%s` (profiles/r03_bench_traffic.json): "
+                             "%.0f positions per trunk launch there; gfx950 FETCH_SIZE x2 correction applied to the "
+                             "16 B/lane weight reads" % (tj["command"], tj["kernels"]["k_trunk16"]["positions_per_launch"]))
+        except Exception:
+            pass
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
         # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
         net_s = prof["union_ms"] * 1e-3
@@ -448,8 +457,8 @@ def main():
                 "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic if wide and prec != "f32" else None,
-                "traffic_basis": "PMC FETCH_SIZE/WRITE_SIZE of a full launch of 4096 positions "
-                                 "(profiles/%s); algorithmic bytes of that launch: 1.18 MB" % traffic_file,
+                "traffic_basis": traffic_basis,
+                "algorithmic_bytes_per_launch": round(prof["evals"] / max(1, prof["net_launches"]) * (24 + 4 * (args.board ** 2 + 2))),
                 "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"
                                % (args.profile_steps, prof["games"], prof["wall_s"]),
                 "frac_mfma_issue": round(achieved * issued / peak, 4),
@@ -467,6 +476,23 @@ def main():
                 "tree_kernels_ms": round(prof["tree_ms"], 2), "tree_launches": prof["tree_launches"],
             },
             "cpu_baseline": None,
+        }
+        # the rollout (tree search) kernel against the HBM roofline: algorithmic bytes of one launch (one simulation of
+        # every game slot of a lane) / its mean duration, measured live in the profiled step (HIP events)
+        tree_us = prof["tree_ms"] * 1e3 / max(1, prof["tree_launches"])
+        tree_bytes = TREE_BYTES_PER_GAME_SIM * (args.games // lanes)
+        tree_gbs = tree_bytes / (tree_us * 1e-6) / 1e9 if tree_us > 0 else 0.0
+        out["roofline_rollout"] = {
+            "kernel": "k_tree (expand + backup of the evaluated leaf, next PUCT descent or ply step; one launch per "
+                      "simulation and lane)",
+            "bound": "hbm", "achieved": round(tree_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(tree_gbs / PEAK_HBM_GBS, 5), "traffic": tree_traffic,
+            "algorithmic_bytes_per_launch": tree_bytes,
+            "bytes_basis": "%d B per game and simulation (24 B leaf out, 264 B result in, ~3 nodes x (32 B + 8 edges x 16 B) "
+                           "read, ~3 path edges rewritten) x %d game slots per lane" % (TREE_BYTES_PER_GAME_SIM, args.games // lanes),
+            "avg_launch_us": round(tree_us, 2), "launches": prof["tree_launches"],
+            "note": "a dependent pointer chase through L2 / Infinity-Cache-resident trees (latency-bound, not bandwidth-"
+                    "bound); it runs concurrently with the other lane's trunk launch",
         }
         # evidence first: if the CPU leg were to be killed the measured line is already on stderr
         print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)

@@ -64,6 +64,17 @@ struct oth_net {
     oth::H3Weights* h3 = nullptr;
 };
 
+// The in-place MFMAs of net_mfma.hip / net_h3.hip are inline asm: hipcc inserts no wait states between a VALU write of a
+// VGPR and an asm MFMA reading it (2 needed on gfx90a+).  Accumulators are zeroed by VALU moves which the compiler likes to
+// sink next to their first use; OTH_PIN_ACC keeps the move of one accumulator in front of this point and
+// OTH_PIN_ACC_END supplies the wait states once for all of them.  tools/check_mfma_hazards.py checks the built objects.
+#define OTH_PIN_ACC(x) asm volatile("" : "+v"(x))
+#define OTH_PIN_ACC_END()                  \
+    do {                                   \
+        asm volatile("s_nop 1" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
 namespace oth {
 int mfma_pack_weights(oth_net* net, int precision);  // net_mfma.hip
 void mfma_free_weights(oth_net* net);

@@ -24,6 +24,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "net.h"
@@ -66,8 +67,15 @@ struct H3Geom {
     static constexpr int NP = CELLS + 1;
     static constexpr int NCO = P * CELLS;             // output cells of a wave
     static constexpr int T = (NCO + 15) / 16;         // 16-cell tiles
-    static constexpr int POSC = (BS + 2) * BS;        // cells of one position incl. a zero row above and below
-    static constexpr int NC = P * POSC + 2;           // + one guard cell at each end (dx = -1 / +1 at the ends)
+    // Cell index of (position p, cell r): 1 + p*POSC + BS + r -- a guard cell, a zero row above, the board, and 16
+    // zero cells (>= a zero row below plus the next position's zero row above) before the next position.  The 16-cell
+    // gap and a chunk stride NC that is a multiple of 16 keep the 16-byte slot of (lane's cell, k-group) congruent to
+    // `tile start + n16` modulo 16 for every lane of a ds_read_b128 group -- also in tiles that straddle two positions
+    // -- so the reads are bank-conflict-free (with POSC = (BS+2)*BS and NC = P*POSC + 2, as in round 2, half of the LDS
+    // cycles of this kernel were bank-conflict cycles: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50).
+    static constexpr int POSC = CELLS + 16;
+    static constexpr int NC = (P * POSC + 2 + 15) / 16 * 16;
+    static_assert(2 * BS <= 16, "the inter-position gap must hold two zero rows");
     static constexpr int HI_BYTES = NKC * NC * 16;    // size of the hi array (= offset of the lo array)
     static constexpr int ACT_BYTES = 2 * HI_BYTES;
     static constexpr int SCRATCH_BYTES = 192 * 4;     // heads
@@ -75,8 +83,17 @@ struct H3Geom {
     static_assert(F * NCO * 4 <= ACT_BYTES, "the fp32 planes of the heads alias the activation arrays");
 };
 
+template <bool INPLACE>
 __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    if constexpr (INPLACE) {
+        // accumulate in place (vDst = SrcC), as k_trunk16 does: no accumulator migration, no WAR wait states.  Inline
+        // asm hides the instruction from hipcc's hazard recogniser: only for the instances tools/check_mfma_hazards.py
+        // finds clean (the 32-filter builds get accumulator copies in front of their MFMAs: they use the builtin).
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        return c;
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
 }
 
 template <int F, int BS, int P, int WPB>
@@ -126,13 +143,14 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         const int ci = t * 16 + n16;
         valid[t] = ci < NCO;
         const int c = valid[t] ? ci : 0;
-        const int p = c / CELLS, r = c % CELLS, y = r / BS, x = r % BS;
-        const int idx = 1 + p * POSC + (y + 1) * BS + x;
+        const int p = c / CELLS, r = c % CELLS, x = r % BS;
+        const int idx = 1 + p * POSC + BS + r;
         x_first[t] = x == 0;
         x_last[t] = x == BS - 1;
         rd_off[t] = (g4 * NC + idx) * 16;                           // B operand: chunk 4*kk + g4 of the source cell
         wr_off[t] = ((g4 >> 1) * NC + idx) * 16 + (g4 & 1) * 8;     // D rows 16*rb + 4*g4 + r: chunk 2*rb + (g4>>1)
     }
+    const int zero_off = (g4 * NC) * 16;   // guard cell 0 of this lane's k-group chunk: always zero
 
     f32x4 acc[NB][T], res[NB][T];
 #pragma unroll
@@ -141,9 +159,12 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         for (int t = 0; t < T; ++t) {
             acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             res[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            OTH_PIN_ACC(acc[b][t]);
         }
+    OTH_PIN_ACC_END();
 
     uint32_t sat_bits = 0;   // largest activation seen (bit pattern); reaching the clamp raises the saturation flag
+#define OTH_SB __builtin_amdgcn_sched_barrier(0)
     for (int layer = 0; layer < a.n_layers; ++layer) {
         const int KK = layer == 0 ? 1 : F / 32;   // k-steps of 32 input channels (stem: planes 0..2 of chunk 0)
         const int nsteps = 9 * KK;
@@ -160,72 +181,98 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                     wh[b] = __builtin_bit_cast(half8, wq[2 * b]);
                     wlo[b] = __builtin_bit_cast(half8, wq[2 * b + 1]);
                 }
-                {   // request the next step's fragments (the last step re-reads its own: harmless)
-                    int ns = kk * 9 + tap + 1;
-                    ns = ns < nsteps ? ns : nsteps - 1;
-#pragma unroll
-                    for (int f = 0; f < NB * 2; ++f) wq[f] = wl[((size_t)ns * NB * 2 + f) * 64];
-                }
+                int ns = kk * 9 + tap + 1;   // the next step's fragments (the last step re-reads its own: harmless)
+                ns = ns < nsteps ? ns : nsteps - 1;
                 const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const int soff = (kk * 4 * NC + dy * BS + dx) * 16;
-                half8 xh[T], xl[T];
+                const int soff = (dy * BS + dx) * 16, koff = kk * 4 * NC * 16;
+                // source address of tile t: lanes whose source column is off the board (first / last column of a row
+                // for dx = -1 / +1) read the zero guard cell instead of zeroing eight fragment registers afterwards
+                auto src_of = [&](int t) -> const char* {
+                    int o = rd_off[t] + soff;
+                    if (dx < 0) o = x_first[t] ? zero_off : o;
+                    if (dx > 0) o = x_last[t] ? zero_off : o;
+                    return act + o + koff;
+                };
+                // Issue order pinned by sched_barrier: the two LDS reads of tile t+1 and the weight loads of the next
+                // step go BETWEEN the 3*NB MFMAs of tile t (one per MFMA slot) instead of in a clump in front of them,
+                // where they left the matrix pipe idle (one wave per SIMD here: nothing else fills the gap).
+                half8 xh[2], xl[2];
+                xh[0] = *(const half8*)src_of(0);
+                xl[0] = *(const half8*)(src_of(0) + HI);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    xh[t] = *(const half8*)(act + rd_off[t] + soff);
-                    xl[t] = *(const half8*)(act + rd_off[t] + soff + HI);
-                    if (dx != 0) {   // the source column is off the board for the first / last column of a row
-                        const bool off = dx < 0 ? x_first[t] : x_last[t];
-                        if (off) {
-                            xh[t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                            xl[t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                        }
+                    const int cur = t & 1, nxt = cur ^ 1;
+                    const char* nsrc = t + 1 < T ? src_of(t + 1) : act;
+                    OTH_SB;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {   // the three split products of one accumulator back to back
+                        acc[b][t] = mfma_h<(F >= 64)>(wh[b], xl[cur], acc[b][t]);
+                        OTH_SB;
+                        if (b == 0 && t + 1 < T) xh[nxt] = *(const half8*)nsrc;
+                        if (t == 0) wq[2 * b] = wl[((size_t)ns * NB * 2 + 2 * b) * 64];
+                        OTH_SB;
+                        acc[b][t] = mfma_h<(F >= 64)>(wh[b], xh[cur], acc[b][t]);
+                        OTH_SB;
+                        if (b == 0 && t + 1 < T) xl[nxt] = *(const half8*)(nsrc + HI);
+                        if (t == 0) wq[2 * b + 1] = wl[((size_t)ns * NB * 2 + 2 * b + 1) * 64];
+                        OTH_SB;
+                        acc[b][t] = mfma_h<(F >= 64)>(wlo[b], xh[cur], acc[b][t]);
+                        OTH_SB;
                     }
                 }
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {   // the three split products of one accumulator back to back
-                        acc[b][t] = mfma_h(wh[b], xl[t], acc[b][t]);
-                        acc[b][t] = mfma_h(wh[b], xh[t], acc[b][t]);
-                        acc[b][t] = mfma_h(wlo[b], xh[t], acc[b][t]);
-                    }
             }
         }
-        // ---- epilogue: undo the weight scale, bias, skip connection (net.py:58-59), ReLU, re-split, rewrite in place
-        const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block
-        const bool set_res = layer == 0 || add_res;
+        // ---- epilogue: undo the weight scale, bias, skip connection (net.py:58-59), ReLU, re-split, rewrite in place.
+        //      add_res / set_res are compile-time flags of three instantiations (no v_cndmask per value).
         const float inv = a.inv[layer];
+        auto epilogue = [&](auto ADD, auto SET) {
+            constexpr bool add_res = decltype(ADD)::value;   // second conv of a block
+            constexpr bool set_res = decltype(SET)::value;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float4 bias = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * g4);
+            for (int b = 0; b < NB; ++b) {
+                const float4 bias = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * g4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    f32x4 v;
+                    v[0] = fmaf(acc[b][t][0], inv, bias.x);
+                    v[1] = fmaf(acc[b][t][1], inv, bias.y);
+                    v[2] = fmaf(acc[b][t][2], inv, bias.z);
+                    v[3] = fmaf(acc[b][t][3], inv, bias.w);
+                    if (add_res) v += res[b][t];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, 60000.f);  // ReLU + f16 range clamp
+                    sat_bits = max(sat_bits, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])),
+                                                 max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
+                    if (set_res) res[b][t] = v;
+                    if (valid[t]) {
+                        half4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            hi[r] = (_Float16)v[r];
+                            lo[r] = (_Float16)(v[r] - (float)hi[r]);
+                        }
+                        char* dst = act + wr_off[t] + b * 2 * NC * 16;
+                        *(half4*)dst = hi;
+                        *(half4*)(dst + HI) = lo;
+                    }
+                }
+            }
+        };
+        if (layer == 0) epilogue(std::false_type{}, std::true_type{});
+        else if (layer & 1) epilogue(std::false_type{}, std::false_type{});
+        else epilogue(std::true_type{}, std::true_type{});
+        // zero the accumulators for the next conv here (not in the epilogue, where they would hold registers), pinned
+        // in front of the wait states the in-place asm MFMAs need after a VALU write (net.h)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                f32x4 v;
-                v[0] = fmaf(acc[b][t][0], inv, bias.x);
-                v[1] = fmaf(acc[b][t][1], inv, bias.y);
-                v[2] = fmaf(acc[b][t][2], inv, bias.z);
-                v[3] = fmaf(acc[b][t][3], inv, bias.w);
-                if (add_res) v += res[b][t];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, 60000.f);  // ReLU + f16 range clamp
-                sat_bits = max(sat_bits, max(max(__float_as_uint(v[0]), __float_as_uint(v[1])),
-                                             max(__float_as_uint(v[2]), __float_as_uint(v[3]))));
-                if (set_res) res[b][t] = v;
                 acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (valid[t]) {
-                    half4 hi, lo;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hi[r] = (_Float16)v[r];
-                        lo[r] = (_Float16)(v[r] - (float)hi[r]);
-                    }
-                    char* dst = act + wr_off[t] + b * 2 * NC * 16;
-                    *(half4*)dst = hi;
-                    *(half4*)(dst + HI) = lo;
-                }
+                OTH_PIN_ACC(acc[b][t]);
             }
-        }
+        OTH_PIN_ACC_END();
     }
+#undef OTH_SB
 
     // ---- heads: the final activations (in `res`, scaled by 2^4) as fp32 planes [channel][output cell], aliasing
     //      the activation arrays (every read of them is done)

@@ -364,7 +364,9 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
 // reads and MFMAs are skipped altogether -- 1/12 of the conv work (zero padding is 16 % of a 3x3 conv on 8x8).
 // =================================================================================================
 using f32x4 = float __attribute__((ext_vector_type(4)));
+template <bool INPLACE = true>
 __device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
+    if constexpr (!INPLACE) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 #ifndef OTH_BUILTIN_MFMA
     // accumulate IN PLACE (vDst = SrcC): the register allocator otherwise moves an accumulator to fresh registers at
     // the head of a chain and pays WAR wait states (s_nop) when the freed registers are reused at once
@@ -398,8 +400,11 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
 #define OTH16_PD 2
 #endif
 #ifndef OTH16_PB
-#define OTH16_PB 2
+#define OTH16_PB 1   // one k-step (8 tiles x 6 MFMAs = 768+ cycles) ahead covers the L2 latency; 2 spills registers
 #endif
+    // in-place asm MFMAs only in the builds tools/check_mfma_hazards.py finds clean: the 4-position build keeps some
+    // accumulators in AGPRs and copies MFMA results there at once, which needs the compiler's own wait states
+    constexpr bool IP = TP <= 2;
     constexpr int PD = (X3 || TP <= 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
     constexpr int PB = OTH16_PB;    // weight k-steps (32 channels) in flight
     constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row); TP = 1: two rows
@@ -458,6 +463,11 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[t][rb][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) OTH_PIN_ACC(acc[t][rb]);
+    OTH_PIN_ACC_END();
 
     {   // stem conv: one k-step of 32
         const uint4* wp = a.stem + ((size_t)wave * 4) * 64 + lane;  // [rb0 hi][rb0 lo][rb1 hi][rb1 lo]
@@ -472,8 +482,8 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
             const half8 xh = *(const half8*)(lds + SCR_OFF + (OTH_TILE_CELL(t) + lane_cell) * 64 + g4 * 16);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                if (X3) acc[t][rb] = mfma32(wlo[rb], xh, acc[t][rb]);
-                acc[t][rb] = mfma32(wh[rb], xh, acc[t][rb]);
+                if (X3) acc[t][rb] = mfma32<IP>(wlo[rb], xh, acc[t][rb]);
+                acc[t][rb] = mfma32<IP>(wh[rb], xh, acc[t][rb]);
             }
         }
     }
@@ -527,7 +537,6 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                         if (add_res) v += res[t][rb][e];
                         v = __builtin_amdgcn_fmed3f(v, 0.f, kActClamp);  // ReLU + f16 range clamp (x <= 3750)
                         if (set_res) res[t][rb][e] = v;
-                        acc[t][rb][e] = 0.f;
                         vs[e] = v;
                     }
                     // saturation watch: non-negative floats order like their bit patterns (one v_max3_u32 per pair)
@@ -568,6 +577,16 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
         OTH_STAMP(2)
         lds_barrier();
         OTH_STAMP(3)
+        // zero the accumulators HERE (they need no registers during the epilogue) and keep the moves in front of the
+        // wait states the in-place asm MFMAs need after a VALU write (net.h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                acc[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                OTH_PIN_ACC(acc[t][rb]);
+            }
+        OTH_PIN_ACC_END();
 #ifdef OTH_STAMPS
         if (a.tl && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256) && layer < 21)
             a.tl[(blockIdx.x ? 64 : 0) + layer * 2] = t0_;
@@ -578,7 +597,11 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
             constexpr int DY = decltype(DYC)::value;
             constexpr int NTV = (DY == 0 || TP == 1) ? NT : NT - NT / 8;  // tiles with in-board source rows
             constexpr int NQ = 4 * NTV;                      // (k-step, tile) fragments of one tap
+#ifdef OTH_ABLATE_TAPS   // diagnostic: 2 of 3 column taps (1.5x fewer MFMAs, everything else unchanged; WRONG results)
+            for (int dxi = 0; dxi < 2; ++dxi) {
+#else
             for (int dxi = 0; dxi < 3; ++dxi) {
+#endif
                 const int tap = (DY + 1) * 3 + dxi;
                 const int xs = cx + dxi - 1;
                 const bool xok = xs >= 0 && xs < 8;
@@ -624,29 +647,37 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     const int sl = q % (PD + 1);
                     OTH_SB;
                     if constexpr (X3) {
-                        acc[t][0] = mfma32(wh[0], xl[sl], acc[t][0]);
+                        acc[t][0] = mfma32<IP>(wh[0], xl[sl], acc[t][0]);
                         OTH_SB;
                         const char* src = pf ? OTH_SRC(q + PD) : lds;
                         OTH_SB;
-                        acc[t][0] = mfma32(wh[0], xh[sl], acc[t][0]);
+                        acc[t][0] = mfma32<IP>(wh[0], xh[sl], acc[t][0]);
                         OTH_SB;
                         if (neww) wq[wslot][0] = wl[(size_t)nstep * 1024];
                         OTH_SB;
-                        acc[t][0] = mfma32(wlo[0], xh[sl], acc[t][0]);
+                        acc[t][0] = mfma32<IP>(wlo[0], xh[sl], acc[t][0]);
                         OTH_SB;
                         if (pf) xh[psl] = *(const half8*)src;
+#ifdef OTH_ABLATE_W       // diagnostic: half the L2 -> CU weight stream (lo fragments not loaded; WRONG results)
+                        if (neww) wq[wslot][1] = wq[wslot][0];
+#else
                         if (neww) wq[wslot][1] = wl[(size_t)nstep * 1024 + 64];
+#endif
                         OTH_SB;
-                        acc[t][1] = mfma32(wlo[1], xh[sl], acc[t][1]);
+                        acc[t][1] = mfma32<IP>(wlo[1], xh[sl], acc[t][1]);
                         OTH_SB;
                         if (pf) xl[psl] = *(const half8*)(src + 256);
                         if (neww) wq[wslot][2] = wl[(size_t)nstep * 1024 + 128];
                         OTH_SB;
-                        acc[t][1] = mfma32(wh[1], xh[sl], acc[t][1]);
+                        acc[t][1] = mfma32<IP>(wh[1], xh[sl], acc[t][1]);
                         OTH_SB;
+#ifdef OTH_ABLATE_W
+                        if (neww) wq[wslot][3] = wq[wslot][2];
+#else
                         if (neww) wq[wslot][3] = wl[(size_t)nstep * 1024 + 192];
+#endif
                         OTH_SB;
-                        acc[t][1] = mfma32(wh[1], xl[sl], acc[t][1]);
+                        acc[t][1] = mfma32<IP>(wh[1], xl[sl], acc[t][1]);
                     } else {
                         if (pf) xh[psl] = *(const half8*)OTH_SRC(q + PD);
                         if (neww) {
@@ -655,7 +686,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                         }
                         OTH_SB;
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) acc[t][rb] = mfma32(wh[rb], xh[sl], acc[t][rb]);
+                        for (int rb = 0; rb < 2; ++rb) acc[t][rb] = mfma32<IP>(wh[rb], xh[sl], acc[t][rb]);
                     }
                     OTH_SB;
                 }
@@ -694,16 +725,16 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                         // sizes.  Each row block therefore always sums in the same order.)
                         const int sl = q % (PD + 1);
                         const int r0 = 0, r1 = 1;
-                        acc[t][r0] = mfma32(wh[r0], xl[sl], acc[t][r0]);
-                        acc[t][r0] = mfma32(wh[r0], xh[sl], acc[t][r0]);
-                        acc[t][r0] = mfma32(wlo[r0], xh[sl], acc[t][r0]);
+                        acc[t][r0] = mfma32<IP>(wh[r0], xl[sl], acc[t][r0]);
+                        acc[t][r0] = mfma32<IP>(wh[r0], xh[sl], acc[t][r0]);
+                        acc[t][r0] = mfma32<IP>(wlo[r0], xh[sl], acc[t][r0]);
                         __builtin_amdgcn_sched_barrier(0);
-                        acc[t][r1] = mfma32(wlo[r1], xh[sl], acc[t][r1]);
-                        acc[t][r1] = mfma32(wh[r1], xh[sl], acc[t][r1]);
-                        acc[t][r1] = mfma32(wh[r1], xl[sl], acc[t][r1]);
+                        acc[t][r1] = mfma32<IP>(wlo[r1], xh[sl], acc[t][r1]);
+                        acc[t][r1] = mfma32<IP>(wh[r1], xh[sl], acc[t][r1]);
+                        acc[t][r1] = mfma32<IP>(wh[r1], xl[sl], acc[t][r1]);
                     } else {
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) acc[t][rb] = mfma32(wh[rb], xh[q % (PD + 1)], acc[t][rb]);
+                        for (int rb = 0; rb < 2; ++rb) acc[t][rb] = mfma32<IP>(wh[rb], xh[q % (PD + 1)], acc[t][rb]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -193,3 +193,21 @@ def test_integration_md_cfg_struct_matches_the_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     hdr_fields = re.findall(r"(?:int32_t|float|double)\s+(\w+);", body)
     assert hdr_fields == [n for n, _ in lib_fields]
+
+
+def test_no_mfma_hazards_in_built_objects():
+    """The in-place MFMAs of the trunk kernels are inline asm, invisible to hipcc's hazard recogniser: the built gfx950
+    code objects must have no VALU write of an MFMA source within two wait states (and no early consumer of an MFMA
+    result).  tools/check_mfma_hazards.py disassembles net_mfma.o / net_h3.o; it needs llvm-objdump from /opt/rocm."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f) for f in ("net_mfma.o", "net_h3.o")]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("object files / llvm-objdump not present (the .o files do not travel to the GPU box)")
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for o in objs:
+        n, bad = mod.check_object(o)
+        assert n > 1000 and not bad, bad[:3]

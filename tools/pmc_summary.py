@@ -9,7 +9,7 @@ import sys
 dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
 every = "--all" in sys.argv
 for d in dirs:
-    for f in sorted(glob.glob(d + "/*/*counter_collection.csv")):
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
