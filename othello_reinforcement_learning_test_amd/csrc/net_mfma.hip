@@ -402,11 +402,23 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
 #ifndef OTH16_PB
 #define OTH16_PB 1   // one k-step (8 tiles x 6 MFMAs = 768+ cycles) ahead covers the L2 latency; 2 spills registers
 #endif
-    // in-place asm MFMAs only in the builds tools/check_mfma_hazards.py finds clean: the 4-position build keeps some
-    // accumulators in AGPRs and copies MFMA results there at once, which needs the compiler's own wait states
-    constexpr bool IP = TP <= 2;
+    // in-place asm MFMAs only in the build that gains from them and that tools/check_mfma_hazards.py finds clean (TP = 2):
+    // the 4-position build keeps some accumulators in AGPRs and copies MFMA results there at once, which needs the
+    // compiler's own wait states
+    constexpr bool IP = TP == 2;
+    // the interleaved issue order pays where two workgroups share a CU and saturate the matrix pipe (TP = 2: -3 %); the
+    // low-latency one-position build (launches <= 256 positions, a CU per workgroup) is 2-4 % faster with round 2's
+    // clumped order and builtin MFMAs (same-session A/B, profiles/r03_trunk_experiments.log), so it keeps them
+#ifdef OTH_CLUMPED
+    constexpr bool ILV = false;
+#else
+    constexpr bool ILV = TP == 2;
+#endif
     constexpr int PD = (X3 || TP <= 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
-    constexpr int PB = OTH16_PB;    // weight k-steps (32 channels) in flight
+    // weight k-steps (32 channels) in flight: a k-step is NT tiles x 6 MFMAs, i.e. 768 cycles at TP = 2 (one ahead covers
+    // the L2 latency; two spill registers) but only 384 at TP = 1, where one ahead stalls every k-step (small engines
+    // lost 25-30 % with it) and registers are plentiful
+    constexpr int PB = TP == 1 ? 2 : OTH16_PB;
     constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row); TP = 1: two rows
     constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
     constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
@@ -621,7 +633,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     if (X3) xl[q] = *(const half8*)(OTH_SRC(q) + 256);
                 }
                 half8 wh[2], wlo[2];
-#ifndef OTH_CLUMPED
+                if constexpr (ILV) {
                 // Interleaved issue order (every statement pinned by sched_barrier): the address arithmetic and the two
                 // LDS reads of tile q+PD and, at a k-step boundary, the four weight loads of k-step +PB are placed BETWEEN
                 // the six MFMAs of tile q -- one per MFMA slot (an MFMA holds the issue port for 8 of its 16 cycles) --
@@ -690,8 +702,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     }
                     OTH_SB;
                 }
-#undef OTH_SB
-#else
+                } else {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (q + PD < NQ) {
@@ -738,7 +749,8 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
+                }
+#undef OTH_SB
 #undef OTH_SRC
 #undef OTH_ROW_OK
 #undef OTH_TILE_OF

@@ -264,8 +264,10 @@ class ParallelSelfPlayWorker:
             for k, v in eng.counters().items():
                 counters[k] = counters.get(k, 0) + v
         games = len(self.last_game_ids) if (self.continuous and self.rng_mode == "device") else num_episodes
-        self.last_stats = {"games": games, "samples": len(data), "seconds": dt,
-                           "games_per_s": games / dt if dt > 0 else float("inf"), **counters}
+        # the engine's counters are cumulative ("games" = every game finished so far): kept under "engine_*" names
+        self.last_stats = {**{"engine_" + k if k == "games" else k: v for k, v in counters.items()},
+                           "games": games, "samples": len(data), "seconds": dt,
+                           "games_per_s": games / dt if dt > 0 else float("inf")}
         if self.verbose:
             print("  Self-Play: %d/%d games | %s samples | %.1fs (%.2f games/s)" %
                   (games, num_episodes, format(len(data), ","), dt, self.last_stats["games_per_s"]))

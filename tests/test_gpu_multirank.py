@@ -29,4 +29,7 @@ def test_bench_multi_rank_rehearsal(rehearsal):
     # the all-gathered tuple count of the last step covers all ranks: ~60 plies per game, ~32 games per rank
     assert cfg["samples_last_step"] > w * 29 * 40
     assert d["roofline"]["launches"] > 0 and d["cpu_baseline"] is None
+    rr = d["roofline_rollout"]           # the tree kernel against the HBM roofline, measured live in the profiled step
+    assert rr["bound"] == "hbm" and rr["unit"] == "GB/s" and rr["achieved"] > 0 and rr["launches"] > 0
+    assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-4
     assert "step 2/2" in err                            # heartbeat lines on stderr

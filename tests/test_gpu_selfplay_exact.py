@@ -308,11 +308,13 @@ def test_worker_continuous_mode_exact_with_cache_and_refresh(pkg):
                                    eval_cache_log2=12)
     np.random.seed(5)
     calls, ids = [], []
-    for want in (12, 5, 20):
+    # the last request (60) exceeds what the history ring sized by the first call can harvest in one step (48): the
+    # worker then plays it in several stream steps and concatenates them
+    for want in (12, 5, 20, 60):
         data = w.execute_episodes(want)
         ids.append(w.last_game_ids.copy())
         calls.append(data)
-        assert len(ids[-1]) >= want
+        assert len(ids[-1]) >= want and w.last_stats["games"] == len(ids[-1])
         w.batch_mcts.evaluator.refresh(force=True)
     all_ids = np.concatenate(ids)
     assert len(set(all_ids.tolist())) == len(all_ids)
