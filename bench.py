@@ -406,7 +406,10 @@ def main():
         # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
         # source row is zero padding (1/12 of the conv work is skipped by the shipped kernel)
         wide = args.filters == 128 and args.board == 8     # k_trunk16 skips the all-padding tiles (1/12 of the work)
-        issued = (3.0 if prec == "f16x3" else 1.0) * (11.0 / 12.0 if (prec != "f32" and wide) else 1.0)
+        # launches of > 256 positions of the wide f16x3 network run the 1-D Winograd F(2,3) trunk (net_wino.hip: 4 MFMAs per 2
+        # outputs instead of 6, no row skip) unless OTH_WINO=0 keeps them on the direct kernel k_trunk16
+        wino = wide and prec == "f16x3" and os.environ.get("OTH_WINO", "1") != "0"
+        issued = (3.0 if prec == "f16x3" else 1.0) * ((2.0 / 3.0 if wino else 11.0 / 12.0) if (prec != "f32" and wide) else 1.0)
         peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
         evals_per_game = stats["evals"] / max(1, stats["games"])
         out = {
@@ -452,11 +455,15 @@ def main():
             },
             "roofline": {
                 "kernel": ("k_trunk_f32 (fused ResNet forward, fp32 MFMA)" if prec == "f32" else
+                           "k_trunk_w (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions)" if wino else
                            "k_trunk16 (fused ResNet forward)" if wide else
                            "k_trunk_h3 (fused ResNet forward, one wave per position)"),
                 "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic if wide and prec != "f32" else None,
+                "flops_basis": "ALGORITHMIC FLOPs of the direct 3x3 convolutions (378.03 MFLOP per position), whatever the "
+                               "kernel issues: the Winograd trunk issues 2.0 MFMA FLOPs per algorithmic FLOP, the direct "
+                               "one 2.75",
                 "traffic_basis": traffic_basis,
                 "algorithmic_bytes_per_launch": round(prof["evals"] / max(1, prof["net_launches"]) * (24 + 4 * (args.board ** 2 + 2))),
                 "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"

@@ -45,6 +45,7 @@ struct HeadParams {
 struct MfmaWeights;  // net_mfma.hip
 struct F32Weights;   // net_f32.hip
 struct H3Weights;    // net_h3.hip
+struct WinoWeights;  // net_wino.hip
 
 }  // namespace oth
 
@@ -62,6 +63,8 @@ struct oth_net {
     oth::MfmaWeights* mfma = nullptr;
     // fp16-split MFMA path, one wave per position (32 / 64 filters, 8x8 and 6x6): net_h3.hip
     oth::H3Weights* h3 = nullptr;
+    // 1-D Winograd F(2,3) build of the 128-filter 8x8 trunk (fp16-split arithmetic): net_wino.hip
+    oth::WinoWeights* wino = nullptr;
 };
 
 // The in-place MFMAs of net_mfma.hip / net_h3.hip are inline asm: hipcc inserts no wait states between a VALU write of a
@@ -84,6 +87,10 @@ int h3_pack_weights(oth_net* net);  // net_h3.hip
 void h3_free_weights(oth_net* net);
 int h3_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
                const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
+int wino_pack_weights(oth_net* net);  // net_wino.hip
+void wino_free_weights(oth_net* net);
+int wino_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
+                 const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 int f32_pack_weights(oth_net* net);  // net_f32.hip
 void f32_free_weights(oth_net* net);
 int f32_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "net.h"
 #include "net_heads.h"
 
@@ -87,6 +89,7 @@ static void net_free_device(oth_net* net) {
     f32_free_weights(net);
     h3_free_weights(net);
     mfma_free_weights(net);
+    wino_free_weights(net);
 }
 
 extern "C" {
@@ -179,6 +182,14 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
     int r = precision == OTH_PREC_F32 ? f32_pack_weights(net)
                                       : (wide ? mfma_pack_weights(net, precision) : h3_pack_weights(net));
     if (r != OTH_OK) return r;
+    // A 128-filter 8x8 network in f16x3 runs the 1-D Winograd F(2,3) trunk (net_wino.hip: 1.375x fewer MFMAs, +9 % games/s
+    // on the bench; its one-position build serves the launches of <= 256 positions, so a position's outputs do not depend
+    // on the launch size); OTH_WINO=0 keeps the direct kernel (k_trunk16) -- the A/B switch.
+    const char* wino_env = getenv("OTH_WINO");
+    if (precision == OTH_PREC_F16X3 && wide && net->board == 8 && !(wino_env && atoi(wino_env) == 0)) {
+        r = wino_pack_weights(net);
+        if (r != OTH_OK) return r;
+    }
     net->precision = precision;
     return OTH_OK;
 }
@@ -192,6 +203,7 @@ int oth_net_forward_bits(oth_net* net, const uint64_t* sb, const uint64_t* ob, c
     OTH_BIND(net->device);
     if (net->precision == OTH_PREC_F32) return f32_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     if (net->h3) return h3_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
+    if (net->wino) return wino_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     return mfma_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
 }
 

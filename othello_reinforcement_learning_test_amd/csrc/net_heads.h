@@ -7,7 +7,7 @@ namespace oth {
 // ------------------------------------------------------------------------------------------------
 // heads (fp32 VALU), shared by both trunk kernels.  `act` = final trunk activation of ONE position
 // in LDS as [64 cells][F] floats with row stride `ld` floats; scratch >= 128+64+256+72 floats.
-// All 256 threads of the block must call this.  (net.py:83-96 policy, net.py:119-136 value)
+// All threads of the block (256 or 512) must call this.  (net.py:83-96 policy, net.py:119-136 value)
 // ------------------------------------------------------------------------------------------------
 __device__ inline void heads_forward(const HeadParams& hp, int F, const float* act, int ld, float* scratch,
                               float* logp65, float* v1) {
@@ -37,7 +37,7 @@ __device__ inline void heads_forward(const HeadParams& hp, int F, const float* a
         }
     }
     __syncthreads();
-    {   // value fc1: 256 outputs, one per thread
+    if (t < 256) {   // value fc1: 256 outputs, one per thread (a 512-thread caller's upper half only takes the barriers)
         const float* w = hp.vfc1_w + t * 64;
         float acc = hp.vfc1_b[t];
         for (int i = 0; i < 64; ++i) acc = fmaf(w[i], vf[i], acc);

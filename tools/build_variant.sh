@@ -10,11 +10,11 @@ out=$root/build/$name
 mkdir -p "$out"
 make -s -j4 -C "$csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
-for f in net_mfma net_h3; do
+for f in net_mfma net_h3 net_wino; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$csrc/$f.hip" -o "$out/$f.o" &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libothello_mi355x.so" "$out/net_mfma.o" "$out/net_h3.o" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libothello_mi355x.so" "$out/net_mfma.o" "$out/net_h3.o" "$out/net_wino.o" \
   "$csrc/rules_api.o" "$csrc/net.o" "$csrc/net_f32.o" "$csrc/engine.o" "$csrc/replay_ops.o"
 rm -f "$out"/*.o
 echo "built $out/libothello_mi355x.so"
