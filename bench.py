@@ -390,11 +390,12 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r03_bench_traffic.json")) as f:
                 tj = json.load(f)
-            traffic = tj["kernels"]["k_trunk16"]["traffic_bytes_per_launch"]
+            tk = tj["kernels"].get("trunk") or tj["kernels"]["k_trunk16"]
+            traffic = tk["traffic_bytes_per_launch"]
             tree_traffic = tj["kernels"]["k_tree"]["traffic_bytes_per_launch"]
             traffic_basis = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `%s` (profiles/r03_bench_traffic.json): "
-                             "%.0f positions per trunk launch there; gfx950 FETCH_SIZE x2 correction applied to the "
-                             "16 B/lane weight reads" % (tj["command"], tj["kernels"]["k_trunk16"]["positions_per_launch"]))
+                             "kernel %s, %.0f positions per trunk launch there; gfx950 FETCH_SIZE x2 correction applied to the "
+                             "16 B/lane weight reads" % (tj["command"], tk["kernel"], tk["positions_per_launch"]))
         except Exception:
             pass
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the

@@ -91,6 +91,11 @@ __device__ __forceinline__ f32x4 wmfma(half8 a, half8 b, f32x4 c) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     return c;
 }
+__device__ __forceinline__ f32x4 wmfma0(half8 a, half8 b) {   // first product of a chain: C is the inline constant 0
+    f32x4 c;
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+    return c;
+}
 __device__ __forceinline__ void wbarrier() {   // LDS-only barrier: global weight prefetches stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             hi[r] = (_Float16)V[xi][r];
-                            lo[r] = (_Float16)(V[xi][r] - (float)hi[r]);
+                            lo[r] = (_Float16)fmaf((float)hi[r], -1.0f, V[xi][r]);   // exact; v_fma_mix_f32 takes the f16 directly
                         }
                         char* dst = lds + wr_off[nt] + xi * kWTile;
                         *(half4*)dst = hi;
@@ -376,14 +381,6 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         OTH_WSTAMP(2)
         wbarrier();
         OTH_WSTAMP(1)
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[xi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                OTH_PIN_ACC(acc[xi][nt]);
-            }
-        OTH_PIN_ACC_END();
 
         // ---------------- conv `layer+1` in the Winograd domain: 12 groups (row tap d, k-step kk) x 16 steps (N-tile,
         // xi) x 3 split products.  One straight-line software pipeline over all 192 steps: the two LDS reads of step
@@ -424,7 +421,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                 const half8 wh = __builtin_bit_cast(half8, wq[grp & 1][2 * xi]);
                 const half8 wlo = __builtin_bit_cast(half8, wq[grp & 1][2 * xi + 1]);
                 OTH_WSB;
-                acc[xi][nt] = wmfma(wh, xl[sl], acc[xi][nt]);
+                if (q < GS) acc[xi][nt] = wmfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
+                else acc[xi][nt] = wmfma(wh, xl[sl], acc[xi][nt]);
                 OTH_WSB;
                 if (q + PD < QT) xh[psl] = *(const half8*)src_of(q + PD);
                 OTH_WSB;

@@ -31,10 +31,10 @@ line = [l for l in open(out + "/fetch.json") if l.startswith("{")][-1]
 ppl = json.loads(line)["roofline"]["positions_per_launch"]
 res = {"command": cmd, "source": "rocprofv3 --kernel-trace --pmc, one pass per counter group, per-launch means over all launches of the run", "kernels": {}}
 for kern, v in vals.items():
-    key = "k_trunk16" if ("k_trunk16" in kern or "k_trunk_w" in kern) else ("k_tree" if kern.startswith("oth::k_tree<1") else None)
+    key = "trunk" if ("k_trunk16" in kern or "k_trunk_w" in kern) else ("k_tree" if kern.startswith("oth::k_tree<1") else None)
     if key is None or "FETCH_SIZE" not in v:
         continue
-    wide = key == "k_trunk16"   # 16 B/lane coalesced weight reads: FETCH_SIZE counts 64 B per 128-B request on gfx950
+    wide = key == "trunk"   # 16 B/lane coalesced weight reads: FETCH_SIZE counts 64 B per 128-B request on gfx950
     rd = v["FETCH_SIZE"] * 1024 * (2 if wide else 1)
     res["kernels"][key] = {
         "kernel": kern, "launches": v["launches"], "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v.get("WRITE_SIZE"),

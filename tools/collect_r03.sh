@@ -15,13 +15,15 @@ stats)    # rocprofv3 --kernel-trace --stats of bench.py with the hooks on every
   db=$(find /tmp/prof_r03 -name "*.db" | head -1)
   python3 tools/rocpd_stats.py "$db" > $O/bench_kernel_stats.csv; head -4 $O/bench_kernel_stats.csv | cut -c1-150; rm -rf /tmp/prof_r03 ;;
 pmc)
-  tools/pmc_netbench.sh 10x128x8:f16x3 k16_tp2 > $O/trunk_pmc_tp2.txt 2>&1
-  OTH_TRUNK_TP=4 tools/pmc_netbench.sh 10x128x8:f16x3 k16_tp4 > $O/trunk_pmc_tp4.txt 2>&1
+  tools/pmc_netbench.sh 10x128x8:f16x3 wino > $O/trunk_pmc_wino.txt 2>&1
+  OTH_WINO=0 tools/pmc_netbench.sh 10x128x8:f16x3 k16_tp2 > $O/trunk_pmc_tp2.txt 2>&1
+  OTH_WINO=0 OTH_TRUNK_TP=4 tools/pmc_netbench.sh 10x128x8:f16x3 k16_tp4 > $O/trunk_pmc_tp4.txt 2>&1
   tools/pmc_netbench.sh 5x64x6:f16x3 h3_6 > $O/h3_pmc_5x64x6.txt 2>&1
   tools/pmc_netbench.sh 5x64x8:f16x3 h3_8 > $O/h3_pmc_5x64x8.txt 2>&1
-  tools/bench_pmc.sh > $O/bench_pmc.txt 2>&1; cp gpurun_out/r03_bench_traffic.json $O/ ; tail -3 $O/trunk_pmc_tp2.txt | cut -c1-200 ;;
+  tools/bench_pmc.sh > $O/bench_pmc.txt 2>&1; cp gpurun_out/r03_bench_traffic.json $O/ ; tail -3 $O/trunk_pmc_wino.txt | cut -c1-200 ;;
 nets)
-  python3 tools/netbench.py 2>&1 | grep -v amdgpu > $O/netbench.log; head -3 $O/netbench.log ;;
+  python3 tools/netbench.py 2>&1 | grep -v amdgpu > $O/netbench.log; head -3 $O/netbench.log
+  OTH_WINO=0 python3 tools/netbench.py --nets 10x128x8:f16x3 2>&1 | grep -v amdgpu | sed "s/$/   [OTH_WINO=0: direct kernel k_trunk16]/" >> $O/netbench.log ;;
 configs)
   bash tools/configs_table.sh > $O/configs_table.jsonl 2> $O/configs_table.err; python3 tools/print_bench_lines.py $O/configs_table.jsonl ;;
 small)
