@@ -103,6 +103,10 @@ typedef struct oth_net oth_net;
 #define OTH_PREC_F16X3 1   /* MFMA, fp16 hi/lo split of both operands, fp32 accumulate (fp32-equivalent): 32 / 64 / 128
                               filters on 8x8 and 6x6 */
 #define OTH_PREC_F16 2     /* MFMA, single fp16 pass (fast; NOT within the 1e-4 parity tolerance in general); 128 filters, 8x8 */
+#define OTH_PREC_F16X3_DIRECT 3 /* the same fp16 hi/lo split arithmetic as OTH_PREC_F16X3 on the DIRECT 3x3 convolution kernel
+                                 * (k_trunk16) instead of the 1-D Winograd one (k_trunk_w): 128 filters on 8x8 only; the A/B
+                                 * partner of the default and an independent cross-check of it (same tolerance, different
+                                 * summation) */
 
 /* net.py:157-180 __init__(num_blocks, num_filters, board_size).  board_size 8 or 6 (configs/debug_6x6.yaml);
  * num_filters 16, 32, 64 or 128.  A 6x6 network takes positions as bit i = row*6 + col (i < 36) and returns

@@ -14,8 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OTHELLO_MI355X_LIB: A/B-testing hook for kernel work (another build of the same library)
 LIB_PATH = os.environ.get("OTHELLO_MI355X_LIB") or os.path.join(_HERE, "libothello_mi355x.so")
 
-OTH_PREC_F32, OTH_PREC_F16X3, OTH_PREC_F16 = 0, 1, 2
-PRECISIONS = {"f32": OTH_PREC_F32, "f16x3": OTH_PREC_F16X3, "f16": OTH_PREC_F16}
+OTH_PREC_F32, OTH_PREC_F16X3, OTH_PREC_F16, OTH_PREC_F16X3_DIRECT = 0, 1, 2, 3
+# "f16x3": the default for 32 / 64 / 128 filters (128 on 8x8: the 1-D Winograd trunk); "f16x3_direct": the same arithmetic
+# on the direct-convolution kernel (128 filters on 8x8 only)
+PRECISIONS = {"f32": OTH_PREC_F32, "f16x3": OTH_PREC_F16X3, "f16": OTH_PREC_F16, "f16x3_direct": OTH_PREC_F16X3_DIRECT}
 
 
 class OthelloHipError(RuntimeError):

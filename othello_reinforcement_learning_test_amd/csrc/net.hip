@@ -148,7 +148,8 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
               "oth_net_load_state: got %lld floats, a %dx%d network on a %dx%d board has %lld", (long long)n_floats,
               net->blocks, net->filters, net->board, net->board,
               (long long)state_floats(net->blocks, net->filters, net->board));
-    OTH_CHECK(precision == OTH_PREC_F32 || precision == OTH_PREC_F16X3 || precision == OTH_PREC_F16,
+    OTH_CHECK(precision == OTH_PREC_F32 || precision == OTH_PREC_F16X3 || precision == OTH_PREC_F16 ||
+                  precision == OTH_PREC_F16X3_DIRECT,
               "oth_net_load_state: unknown precision %d", precision);
     // fp16-split kernels: 128 filters on 8x8 (k_trunk16: f16x3 and the single-pass f16), 32 / 64 filters on either
     // board (k_trunk_h3: f16x3 only); everything else runs the exact-fp32 MFMA kernel

@@ -944,7 +944,7 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
         attr_set = true;
     }
-    const bool x3 = net->precision == OTH_PREC_F16X3;
+    const bool x3 = net->precision == OTH_PREC_F16X3 || net->precision == OTH_PREC_F16X3_DIRECT;
     const char* tpe = getenv("OTH_TRUNK_TP");
     // default: two 2-position workgroups per CU for the fp16x3 build; the single-pass build runs 4 positions per
     // workgroup (its TP = 2 instantiation spills registers)

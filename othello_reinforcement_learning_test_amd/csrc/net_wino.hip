@@ -115,7 +115,7 @@ __device__ __forceinline__ float quad_next(float v) {
 // workgroup per CU nothing overlaps the heads, and the shared heads_forward (one position at a time, 256 threads, FC
 // rows read with a 256-byte stride per lane) took ~50 k cycles per position there -- a fifth of this kernel.  Here:
 // the 1x1-conv weights staged in LDS, the FC weights transposed on the host so that lanes read consecutive outputs,
-// both positions at once.  act: fp32 [128 cells][128 channels]; scratch: 1 424 floats of LDS.
+// both positions at once.  act: fp32 [128 cells][128 channels]; scratch: 1 568 floats of LDS.
 __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* __restrict__ pfc_wt,
                                              const float* __restrict__ vfc1_wt, const float* act, float* scratch,
                                              bool live1, float* __restrict__ logp, float* __restrict__ vout) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
     float* w3 = scratch;             // [128][3]: policy conv 0, policy conv 1, value conv
     float* feat = scratch + 384;     // [2 positions][192]: policy features (channel, cell) then value features
     float* h1 = scratch + 768;       // [2][256]
-    float* lg = scratch + 1280;      // [2][72]
+    float* lgp = scratch + 1280;     // [2][2][72]: partial logits of the policy FC (two input halves)
     if (t < 384) {
         const int i = t / 3, k = t % 3;
         w3[t] = k < 2 ? hp.pconv_w[i * 2 + k] : hp.vconv_w[i];
@@ -142,36 +142,49 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
         feat[p * 192 + k * 64 + cell] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    {
-        const int p = t >> 8, o = t & 255;
-        const float* f = feat + p * 192;
-        float acc = hp.vfc1_b[o];
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) acc = fmaf(vfc1_wt[i * 256 + o], f[128 + i], acc);
-        h1[p * 256 + o] = acc > 0.f ? acc : 0.f;
-        if (o < 65) {
-            float s = hp.pfc_b[o];
-#pragma unroll 8
-            for (int i = 0; i < 128; ++i) s = fmaf(pfc_wt[i * 65 + o], f[i], s);
-            lg[p * 72 + o] = s;
+    // both FCs read L2-resident weights (97 KB): every weight is loaded ONCE and used for both positions, the loops are
+    // fully unrolled (64 independent loads in flight per thread); threads 0..255 do the value FC1 (one output each),
+    // threads 256..385 the policy FC (65 outputs x two halves of the 128 inputs)
+    if (t < 256) {
+        float a0 = hp.vfc1_b[t], a1 = a0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float w = vfc1_wt[i * 256 + t];
+            a0 = fmaf(w, feat[128 + i], a0);
+            a1 = fmaf(w, feat[192 + 128 + i], a1);
         }
+        h1[t] = a0 > 0.f ? a0 : 0.f;
+        h1[256 + t] = a1 > 0.f ? a1 : 0.f;
+    } else if (t < 256 + 130) {
+        const int u = t - 256, o = u % 65, part = u / 65;
+        float s0 = part == 0 ? hp.pfc_b[o] : 0.f, s1 = s0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float w = pfc_wt[(part * 64 + i) * 65 + o];
+            s0 = fmaf(w, feat[part * 64 + i], s0);
+            s1 = fmaf(w, feat[192 + part * 64 + i], s1);
+        }
+        lgp[part * 72 + o] = s0;
+        lgp[(2 + part) * 72 + o] = s1;
     }
     __syncthreads();
     if ((t & 255) < 64) {   // waves 0 and 4: log_softmax over the 65 logits and the fc2 dot product of their position
         const int p = t >> 8, l = t & 63;
-        const float* g = lg + p * 72;
-        float m = fmaxf(g[l], l == 0 ? g[64] : -INFINITY);
+        const float* gp = lgp + p * 2 * 72;
+        const float gl = gp[l] + gp[72 + l];
+        const float g64 = gp[64] + gp[72 + 64];
+        float m = fmaxf(gl, l == 0 ? g64 : -INFINITY);
         for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        float s = expf(g[l] - m) + (l == 0 ? expf(g[64] - m) : 0.f);
+        float s = expf(gl - m) + (l == 0 ? expf(g64 - m) : 0.f);
         for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
         const float lse = logf(s);
         float acc = 0.f;
         for (int i = l; i < 256; i += 64) acc = fmaf(hp.vfc2_w[i], h1[p * 256 + i], acc);
         for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
         if (p == 0 || live1) {
-            logp[p * 65 + l] = g[l] - m - lse;
+            logp[p * 65 + l] = gl - m - lse;
             if (l == 0) {
-                logp[p * 65 + 64] = g[64] - m - lse;
+                logp[p * 65 + 64] = g64 - m - lse;
                 vout[p] = tanhf(acc + hp.vfc2_b[0]);
             }
         }
@@ -188,6 +201,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                                                     int64_t n, const int32_t* __restrict__ n_valid,
                                                     float* __restrict__ logp, float* __restrict__ vout) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef OTH_STAMPS
+    const unsigned long long tentry_ = w_clk();
+#endif
     int64_t nv = n;
     if (n_valid) {
         const int64_t k = *n_valid;
@@ -452,7 +468,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         o[4] = w_clk() - tstart_;
         o[5] = w_realclk() - rstart_;
         o[6] = rstart_;
+        o[7] = tstart_ - tentry_;   // prologue + stem
     }
+    const unsigned long long theads_ = w_clk();
 #endif
 
     // ---------------- heads (fp32 VALU): final activations (in `res`, x 2^4) -> LDS [128 cells][128] f32, then the
@@ -471,6 +489,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     __syncthreads();
     heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 65536), TP == 2 && pos0 + 1 < nv,
                  logp + pos0 * 65, vout + pos0);
+#ifdef OTH_STAMPS
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + 3] = w_clk() - theads_;   // (overwrites the conv sum)
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -630,8 +651,10 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
         const double nw = (double)dbg_grid * 8;
         fprintf(stderr, "[wino stamps] in-kernel clock %.3f GHz; first start -> last trunk end %.3f ms\n", sm[4] / sm[5] * 0.1,
                 (double)(r1 - r0) * 1e-5);
-        fprintf(stderr, "[wino stamps] per-wave cycles: prefetch %.0f | barriers %.0f | epilogue %.0f | conv %.0f | total %.0f\n",
-                sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw);
+        double pro = 0;
+        for (size_t w = 0; w < (size_t)dbg_grid * 8; ++w) pro += (double)h[w * 8 + 7];
+        fprintf(stderr, "[wino stamps] per-wave cycles: prefetch %.0f | barriers %.0f | epilogue %.0f | heads %.0f | layers total %.0f | prologue+stem %.0f\n",
+                sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, pro / nw);
         (void)hipFree(a.dbg);
     }
 #endif

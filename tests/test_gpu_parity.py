@@ -275,7 +275,8 @@ def test_net_forward_vs_reference_outputs(pkg, golden, seed):
     xd = torch.from_numpy(x).cuda()
     for nb, nf in NETS:
         tag, net = _golden_net(pkg, g, seed, nb, nf)
-        precs = ["f32"] + (["f16x3"] if nf in (32, 64, 128) else [])
+        # 128 filters: "f16x3" is the Winograd trunk (k_trunk_w), "f16x3_direct" the direct-convolution one (k_trunk16)
+        precs = ["f32"] + (["f16x3"] if nf in (32, 64, 128) else []) + (["f16x3_direct"] if nf == 128 else [])
         for prec in precs:
             ev = pkg.HipResNetEvaluator(net, precision=prec)
             logp, v = ev.forward_planes(xd)
@@ -398,17 +399,26 @@ def test_trunk_kernel_variants_agree(pkg):
         rl, rv = net.cuda()(pkg.DeviceBoards.tensor_input(ds, do))
     net.cpu()
     outs = []
-    old = {k: os.environ.get(k) for k in ("OTH_MFMA_SHAPE", "OTH_TRUNK_TP")}
+    old = {k: os.environ.get(k) for k in ("OTH_MFMA_SHAPE", "OTH_TRUNK_TP", "OTH_WINO_TP")}
     try:
-        for shape, tp in (("16", "2"), ("16", "1"), ("16", "4"), ("32", "4")):
+        for shape, tp in (("16", "2"), ("16", "1"), ("16", "4"), ("32", "4")):   # the direct-convolution builds
             os.environ["OTH_MFMA_SHAPE"], os.environ["OTH_TRUNK_TP"] = shape, tp
-            for prec in (("f16x3",) if tp == "1" else ("f16x3", "f16")):   # the one-position build is f16x3 only
+            for prec in (("f16x3_direct",) if tp == "1" else ("f16x3_direct", "f16")):   # the one-position build is f16x3 only
                 ev = pkg.HipResNetEvaluator(net, precision=prec)
                 logp, v = ev.forward_bits(ds, do, lg)
-                tol = 1e-4 if prec == "f16x3" else 2e-3   # single f16 pass is NOT parity-grade
+                tol = 1e-4 if prec == "f16x3_direct" else 2e-3   # single f16 pass is NOT parity-grade
                 assert (logp - rl).abs().max().item() < tol and (v - rv).abs().max().item() < tol, (shape, tp, prec)
-                if prec == "f16x3":
+                if prec == "f16x3_direct":
                     outs.append(logp)
+        wino = []
+        for tp in ("1", "2"):   # the Winograd trunk, one- and two-position builds: bit-identical to each other
+            os.environ["OTH_WINO_TP"] = tp
+            ev = pkg.HipResNetEvaluator(net, precision="f16x3")
+            logp, v = ev.forward_bits(ds, do, lg)
+            assert (logp - rl).abs().max().item() < 1e-4 and (v - rv).abs().max().item() < 1e-4, ("wino", tp)
+            wino.append((logp, v))
+            outs.append(logp)
+        assert torch.equal(wino[0][0], wino[1][0]) and torch.equal(wino[0][1], wino[1][1])
     finally:
         for k, val in old.items():
             if val is None:
@@ -489,14 +499,14 @@ def test_trunk_on_trained_like_weights(pkg):
     assert rl.exp().max().item() > 0.3 and tl.min().item() > -60   # peaked but sane policies
     noise = (rl.double() - tl).abs().max().item()                  # fp32 arithmetic's own distance from float64
     errs = {}
-    for prec in ("f16x3", "f32", "f16"):
+    for prec in ("f16x3", "f16x3_direct", "f32", "f16"):
         ev = pkg.HipResNetEvaluator(net, precision=prec)
         logp, v = ev.forward_bits(ds, do, lg)
         errs[prec] = ((logp - rl).abs().max().item(), (v - rv).abs().max().item(),
                       (logp.double() - tl).abs().max().item())
-    print("trained-like net: torch fp32 vs float64 %.2e; max |dlogp| vs torch fp32: f16x3 %.2e, f32 %.2e, single f16 %.2e"
-          % (noise, errs["f16x3"][0], errs["f32"][0], errs["f16"][0]))
-    for prec in ("f16x3", "f32"):
+    print("trained-like net: torch fp32 vs float64 %.2e; max |dlogp| vs torch fp32: f16x3 (Winograd) %.2e, f16x3_direct %.2e, "
+          "f32 %.2e, single f16 %.2e" % (noise, errs["f16x3"][0], errs["f16x3_direct"][0], errs["f32"][0], errs["f16"][0]))
+    for prec in ("f16x3", "f16x3_direct", "f32"):
         assert errs[prec][0] < 1e-4 and errs[prec][1] < 1e-4, (prec, errs[prec])
         assert errs[prec][2] < 3 * noise + 1e-6, (prec, errs[prec], noise)
     assert errs["f16"][0] > 1e-4     # why the single pass is not the default
