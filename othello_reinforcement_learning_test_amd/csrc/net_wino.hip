@@ -110,16 +110,24 @@ __device__ __forceinline__ float quad_next(float v) {
 }
 
 #define OTH_WSB __builtin_amdgcn_sched_barrier(0)
+constexpr int kHeadRow = 129;   // floats per cell of the heads' fp32 planes (odd: conflict-free column reads)
 
 // Policy and value heads of BOTH positions by the whole 512-thread workgroup (net.py:83-96, 119-136; fp32 VALU).  With one
 // workgroup per CU nothing overlaps the heads, and the shared heads_forward (one position at a time, 256 threads, FC
 // rows read with a 256-byte stride per lane) took ~50 k cycles per position there -- a fifth of this kernel.  Here:
 // the 1x1-conv weights staged in LDS, the FC weights transposed on the host so that lanes read consecutive outputs,
-// both positions at once.  act: fp32 [128 cells][128 channels]; scratch: 1 568 floats of LDS.
+// both positions at once.  act: fp32 [128 cells][kHeadRow = 129 floats: 128 channels + 1 pad]; scratch: 1 568 floats of LDS.
 __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* __restrict__ pfc_wt,
                                              const float* __restrict__ vfc1_wt, const float* act, float* scratch,
-                                             bool live1, float* __restrict__ logp, float* __restrict__ vout) {
+                                             bool live1, float* __restrict__ logp, float* __restrict__ vout,
+                                             unsigned long long* hst = nullptr) {
     const int t = threadIdx.x;
+#ifdef OTH_STAMPS
+    unsigned long long h0_ = w_clk();
+#define OTH_HST(i) { const unsigned long long h1_ = w_clk(); if (hst) hst[i] = h1_ - h0_; h0_ = h1_; }
+#else
+#define OTH_HST(i)
+#endif
     float* w3 = scratch;             // [128][3]: policy conv 0, policy conv 1, value conv
     float* feat = scratch + 384;     // [2 positions][192]: policy features (channel, cell) then value features
     float* h1 = scratch + 768;       // [2][256]
@@ -131,17 +139,23 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
     __syncthreads();
     if (t < 384) {
         const int p = t / 192, rem = t % 192, k = rem >> 6, cell = rem & 63;
-        const float* a = act + (size_t)(p * 64 + cell) * 128;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 128; ++i) {
-            const int ii = (i + cell) & 127;   // rotate the start per lane: conflict-free LDS rows
-            acc = fmaf(a[ii], w3[ii * 3 + k], acc);
+        const float* a = act + (size_t)(p * 64 + cell) * kHeadRow;
+        // rows of 129 floats: lane = cell reads a[i] at bank (cell + i) mod 32 -- conflict-free WITHOUT a per-lane
+        // rotation, so both LDS reads of an iteration have immediate offsets (the weight read is a broadcast) and an
+        // iteration is 2 reads + 1 fma instead of ~10 instructions of address arithmetic.  (The weights as scalar loads
+        // from global memory instead: slower, 3.7 k vs 2.8 k cycles -- scalar-cache misses.)
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll 16
+        for (int i = 0; i < 128; i += 2) {
+            p0 = fmaf(a[i], w3[i * 3 + k], p0);
+            p1 = fmaf(a[i + 1], w3[(i + 1) * 3 + k], p1);
         }
+        float acc = p0 + p1;
         acc += k < 2 ? hp.pconv_b[k] : hp.vconv_b[0];
         feat[p * 192 + k * 64 + cell] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
+    OTH_HST(0)
     // both FCs read L2-resident weights (97 KB): every weight is loaded ONCE and used for both positions, the loops are
     // fully unrolled (64 independent loads in flight per thread); threads 0..255 do the value FC1 (one output each),
     // threads 256..385 the policy FC (65 outputs x two halves of the 128 inputs)
@@ -167,6 +181,7 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
         lgp[part * 72 + o] = s0;
         lgp[(2 + part) * 72 + o] = s1;
     }
+    OTH_HST(1)
     __syncthreads();
     if ((t & 255) < 64) {   // waves 0 and 4: log_softmax over the 65 logits and the fc2 dot product of their position
         const int p = t >> 8, l = t & 63;
@@ -484,13 +499,26 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
             const int cell = (nt >> 1) * 64 + ((nt & 1) * 4 + row4) * 8 + 2 * j + e;
             const float us = 1.0f / kWActScale;
             const f32x4 v = res[nt][e];
-            *(float4*)(lds + (size_t)cell * 512 + (size_t)ch0 * 4) = make_float4(v[0] * us, v[1] * us, v[2] * us, v[3] * us);
+            float* dst = (float*)lds + (size_t)cell * kHeadRow + ch0;   // odd row stride: four scalar stores
+            dst[0] = v[0] * us;
+            dst[1] = v[1] * us;
+            dst[2] = v[2] * us;
+            dst[3] = v[3] * us;
         }
     __syncthreads();
-    heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 65536), TP == 2 && pos0 + 1 < nv,
-                 logp + pos0 * 65, vout + pos0);
 #ifdef OTH_STAMPS
-    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + 3] = w_clk() - theads_;   // (overwrites the conv sum)
+    unsigned long long hst_[2] = {0, 0};
+    const unsigned long long tpre_ = w_clk() - theads_;   // res -> LDS planes + barriers
+    heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
+                 logp + pos0 * 65, vout + pos0, hst_);
+    if (a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[3] = w_clk() - theads_;   // (overwrites the conv sum)
+        o[0] = tpre_; o[1] = hst_[0]; o[2] = hst_[1];   // (overwrite prefetch / barriers / epilogue sums)
+    }
+#else
+    heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
+                 logp + pos0 * 65, vout + pos0);
 #endif
 }
 
@@ -653,7 +681,7 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
                 (double)(r1 - r0) * 1e-5);
         double pro = 0;
         for (size_t w = 0; w < (size_t)dbg_grid * 8; ++w) pro += (double)h[w * 8 + 7];
-        fprintf(stderr, "[wino stamps] per-wave cycles: prefetch %.0f | barriers %.0f | epilogue %.0f | heads %.0f | layers total %.0f | prologue+stem %.0f\n",
+        fprintf(stderr, "[wino stamps] per-wave cycles (x2: averaged over twice the workgroups): planes->LDS %.0f | heads stage 1 (1x1 convs) %.0f | FCs %.0f | heads all %.0f | layers total %.0f | prologue+stem %.0f\n",
                 sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, pro / nw);
         (void)hipFree(a.dbg);
     }
