@@ -390,7 +390,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         // which finishes its convolution at about half time under the oldest-first arbitration -- does it while the
         // younger one still convolves: 3.68 vs 2.69 ms.  A conv step already fills the SIMD's issue port (3 MFMAs x 8
         // cycles + 2 LDS reads + address VALU ~ 48 of its 48 cycles), so the extra VALU is not hidden, it slows the
-        // partner's convolution.)
+        // partner's convolution.  Tried again with the arithmetic at s_setprio 0 and the convolution at s_setprio 3, whole
+        // and for one or two N-tiles only: 3.60 / 2.94 / 3.04 ms -- the 16-64 extra live VGPRs spill at the 256 limit.)
         if (!last) {   // the first weight group of the next convolution: its L2 latency hides under the epilogue
 #pragma unroll
             for (int f = 0; f < 8; ++f) wq[0][f] = wl[(size_t)f * 64];
