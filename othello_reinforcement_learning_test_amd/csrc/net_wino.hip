@@ -109,6 +109,21 @@ __device__ __forceinline__ float quad_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF9, 0xf, 0xf, true));  // [1,2,3,3]
 }
 
+// two fp32 values -> packed f16 (round to nearest even)
+__device__ __forceinline__ uint32_t wpack(float a, float b) {
+    using half2v = _Float16 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, half2v{(_Float16)a, (_Float16)b});
+}
+// packed f16 of (a - hi.lo, b - hi.hi): the low parts of the operand split.  The fp32 difference is exact (hi is a
+// rounded to 11 bits), so the only rounding is the final one to f16 -- the same value as converting hi back, subtracting
+// and converting again, in two instructions.
+__device__ __forceinline__ uint32_t wresid(uint32_t hi, float a, float b) {
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+    return lo;
+}
+
 #define OTH_WSB __builtin_amdgcn_sched_barrier(0)
 constexpr int kHeadRow = 129;   // floats per cell of the heads' fp32 planes (odd: conflict-free column reads)
 
@@ -237,6 +252,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         const int p = tid >> 6, cell = tid & 63, y = cell >> 3, x = cell & 7;
         const bool live = pos0 + p < nv;
         const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
+        // the rows of odd-x output cells are NEGATED: the stem's result then has the form of a Winograd-domain
+        // accumulator set (M0 = y0, M1 = M2 = 0, M3 = -y1) and goes through the same epilogue as every other layer
+        const _Float16 one = (x & 1) ? (_Float16)(-kWActScale) : (_Float16)kWActScale;
         _Float16 vals[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
@@ -245,9 +263,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
             const int s = ok ? yy * 8 + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)kWActScale : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)kWActScale : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)kWActScale : (_Float16)0.0f;
+            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? one : (_Float16)0.0f;
+            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? one : (_Float16)0.0f;
+            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? one : (_Float16)0.0f;
         }
         half8* dst = (half8*)(lds + tid * 64);
 #pragma unroll
@@ -271,9 +289,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
             OTH_PIN_ACC(acc[xi][nt]);
         }
     OTH_PIN_ACC_END();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) res[nt][0] = res[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f};   // the stem "adds" to this
 
-    {   // ---- stem conv (net.py:195), direct: for each N-tile the even-x and the odd-x cells are two column sets, so
-        //      that acc[0] / acc[1] hold y0 / y1 of the Winograd tile -- the layout every epilogue works on
+    {   // ---- stem conv (net.py:195), direct: for each N-tile the even-x and the odd-x cells are two column sets:
+        //      acc[0] = y0 and acc[3] = -y1 of the Winograd tile (acc[1] = acc[2] = 0), so that the output transform
+        //      y0 = M0 + M1 + M2, y1 = M1 - M2 - M3 of the common epilogue returns them exactly
         const uint4* wp = a.stem + (size_t)wave * 2 * 64 + lane;
         const half8 wh = __builtin_bit_cast(half8, wp[0]), wlo = __builtin_bit_cast(half8, wp[64]);
 #pragma unroll
@@ -282,8 +303,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
             for (int e = 0; e < 2; ++e) {
                 const int cell = (nt >> 1) * 64 + ((nt & 1) * 4 + row4) * 8 + 2 * j + e;
                 const half8 xh = *(const half8*)(lds + cell * 64 + g4 * 16);
-                acc[e][nt] = wmfma(wlo, xh, acc[e][nt]);
-                acc[e][nt] = wmfma(wh, xh, acc[e][nt]);
+                acc[3 * e][nt] = wmfma(wlo, xh, acc[3 * e][nt]);
+                acc[3 * e][nt] = wmfma(wh, xh, acc[3 * e][nt]);
             }
     }
 
@@ -325,40 +346,40 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         const uint4* wl = a.w + (size_t)layer * (12 * 8 * 8 * 64) + (size_t)wave * (8 * 64) + lane;
         // ---------------- epilogue of conv `layer`: output transform, scale, bias, skip, ReLU; then the next layer's
         //                  input transform and the hi/lo re-split into V
-        auto epilogue = [&](auto STEM, auto ADD, auto SET, auto LAST) {
-            constexpr bool is_stem = decltype(STEM)::value, add_res = decltype(ADD)::value;
-            constexpr bool set_res = decltype(SET)::value, is_last = decltype(LAST)::value;
+        // Two variants only -- SKIP (even layers: the stem, where the residual registers hold zeros, and the second
+        // convolution of every block: add the residual and keep the result as the new one, IN PLACE) and plain (the
+        // first convolution of a block) -- and the last layer, always a SKIP one, branches around the V part at run
+        // time.  With five compile-time variants in the loop hipcc carried the residual through three register sets
+        // (64 v_mov per even layer).
+        auto epilogue = [&](auto SKIP) {
+            constexpr bool add_res = decltype(SKIP)::value;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                f32x4 y0, y1;
-                if (is_stem) {
-                    y0 = acc[0][nt];
-                    y1 = acc[1][nt];
-                } else {
-                    y0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
-                    y1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
-                }
+                const f32x4 y0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
+                const f32x4 y1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
                 f32x4 v0, v1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float bb = r == 0 ? b4.x : (r == 1 ? b4.y : (r == 2 ? b4.z : b4.w));
                     float t0 = fmaf(y0[r], inv, bb), t1 = fmaf(y1[r], inv, bb);
                     if (add_res) {
-                        t0 += res[nt][0][r];
-                        t1 += res[nt][1][r];
+                        float r0 = res[nt][0][r], r1 = res[nt][1][r];
+                        asm("v_add_f32 %0, %0, %1\n\tv_med3_f32 %0, %0, 0, %2" : "+v"(r0) : "v"(t0), "v"(kWClamp));
+                        asm("v_add_f32 %0, %0, %1\n\tv_med3_f32 %0, %0, 0, %2" : "+v"(r1) : "v"(t1), "v"(kWClamp));
+                        res[nt][0][r] = r0;
+                        res[nt][1][r] = r1;
+                        v0[r] = r0;
+                        v1[r] = r1;
+                    } else {
+                        v0[r] = __builtin_amdgcn_fmed3f(t0, 0.f, kWClamp);
+                        v1[r] = __builtin_amdgcn_fmed3f(t1, 0.f, kWClamp);
                     }
-                    v0[r] = __builtin_amdgcn_fmed3f(t0, 0.f, kWClamp);
-                    v1[r] = __builtin_amdgcn_fmed3f(t1, 0.f, kWClamp);
                 }
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0]), __float_as_uint(v0[1])),
                                              max(__float_as_uint(v0[2]), __float_as_uint(v0[3]))));
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0]), __float_as_uint(v1[1])),
                                              max(__float_as_uint(v1[2]), __float_as_uint(v1[3]))));
-                if (set_res) {
-                    res[nt][0] = v0;
-                    res[nt][1] = v1;
-                }
-                if (!is_last) {
+                if (!last) {
                     f32x4 V[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -370,15 +391,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                     }
 #pragma unroll
                     for (int xi = 0; xi < 4; ++xi) {
-                        half4 hi, lo;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            hi[r] = (_Float16)V[xi][r];
-                            lo[r] = (_Float16)fmaf((float)hi[r], -1.0f, V[xi][r]);   // exact; v_fma_mix_f32 takes the f16 directly
-                        }
+                        uint2 hi, lo;
+                        hi.x = wpack(V[xi][0], V[xi][1]);
+                        hi.y = wpack(V[xi][2], V[xi][3]);
+                        lo.x = wresid(hi.x, V[xi][0], V[xi][1]);
+                        lo.y = wresid(hi.y, V[xi][2], V[xi][3]);
                         char* dst = lds + wr_off[nt] + xi * kWTile;
-                        *(half4*)dst = hi;
-                        *(half4*)(dst + 256) = lo;
+                        *(uint2*)dst = hi;
+                        *(uint2*)(dst + 256) = lo;
                     }
                 }
                 OTH_WSB;   // one N-tile at a time
@@ -399,16 +419,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         OTH_WSTAMP(0)
         wbarrier();   // every wave has finished reading V (or the stem's im2col)
         OTH_WSTAMP(1)
-        if (layer == 0) {
-            if (last) epilogue(T_{}, F_{}, T_{}, T_{});
-            else epilogue(T_{}, F_{}, T_{}, F_{});
-        } else if (last) {
-            epilogue(F_{}, T_{}, T_{}, T_{});
-        } else if (layer & 1) {
-            epilogue(F_{}, F_{}, F_{}, F_{});
-        } else {
-            epilogue(F_{}, T_{}, T_{}, F_{});
-        }
+        if (layer & 1) epilogue(F_{});
+        else epilogue(T_{});
         if (last) break;
         OTH_WSTAMP(2)
         wbarrier();
