@@ -124,6 +124,47 @@ __device__ __forceinline__ uint32_t wresid(uint32_t hi, float a, float b) {
     return lo;
 }
 
+using f32x2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 whalf(const f32x4& v, int h) { return h == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}; }
+__device__ __forceinline__ void wsethalf(f32x4& v, int h, f32x2 x) {
+    v[2 * h] = x.x;
+    v[2 * h + 1] = x.y;
+}
+// packed fp32 (two independent IEEE operations per instruction: the results are those of the scalar forms)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {   // a - b
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_nc(f32x2 a, f32x2 b, f32x2 c) {   // a * b - c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_na(f32x2 a, f32x2 b, f32x2 c) {   // c - a * b
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ void pk_add_relu_inplace(f32x2& r, f32x2 t) {   // r = clamp(r + t, 0, kWClamp) in r's registers
+    asm("v_pk_add_f32 %0, %0, %1" : "+v"(r) : "v"(t));
+    float x = r.x, y = r.y;
+    asm("v_med3_f32 %0, %0, 0, %1" : "+v"(x) : "v"(kWClamp));
+    asm("v_med3_f32 %0, %0, 0, %1" : "+v"(y) : "v"(kWClamp));
+    r = f32x2{x, y};
+}
+
 #define OTH_WSB __builtin_amdgcn_sched_barrier(0)
 constexpr int kHeadRow = 129;   // floats per cell of the heads' fp32 planes (odd: conflict-free column reads)
 
@@ -330,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         }
     }
     const float mask_l = j == 0 ? 0.f : 1.f, mask_r = j == 3 ? 0.f : 1.f;
+    const f32x2 mask_l2 = {mask_l, mask_l}, mask_r2 = {mask_r, mask_r};
 
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
@@ -338,10 +380,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     unsigned long long ph_[4] = {0, 0, 0, 0}, t0_ = w_clk(), tstart_ = t0_;
     const unsigned long long rstart_ = w_realclk();
 #endif
+    float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x 2^4) and 1 / weight scale of the layer in the epilogue
+    float inv = a.inv[0], invn = inv;
     for (int layer = 0; layer < n_layers; ++layer) {
         const bool last = layer == n_layers - 1;
-        float4 b4 = *(const float4*)(a.bias + layer * 128 + ch0);
-        const float inv = a.inv[layer];
+        if (layer > 0) {   // loaded during the previous convolution (at the loop top their L2 latency sat in front of the epilogue)
+            b4 = b4n;
+            inv = invn;
+        }
+        const f32x2 inv2 = {inv, inv};
         // A fragments of conv `layer+1`: group g = dy*4 + kk at wl + g * (8 waves * 8 frags * 64) uint4
         const uint4* wl = a.w + (size_t)layer * (12 * 8 * 8 * 64) + (size_t)wave * (8 * 64) + lane;
         // ---------------- epilogue of conv `layer`: output transform, scale, bias, skip, ReLU; then the next layer's
@@ -355,47 +402,53 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
             constexpr bool add_res = decltype(SKIP)::value;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 y0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
-                const f32x4 y1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
-                f32x4 v0, v1;
+                // packed fp32 throughout (v_pk_add/fma_f32 on the (r, r+1) register pairs; left to hipcc about half of
+                // this was scalarised): 66 instead of 77 VALU instructions per N-tile, the same operation order
+                f32x2 v0[2], v1[2];   // outputs x = 2j, 2j+1 of the tile, channel pairs (0,1) and (2,3)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float bb = r == 0 ? b4.x : (r == 1 ? b4.y : (r == 2 ? b4.z : b4.w));
-                    float t0 = fmaf(y0[r], inv, bb), t1 = fmaf(y1[r], inv, bb);
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 a0 = whalf(acc[0][nt], h), a1 = whalf(acc[1][nt], h), a2 = whalf(acc[2][nt], h),
+                                a3 = whalf(acc[3][nt], h);
+                    const f32x2 bb = h == 0 ? f32x2{b4.x, b4.y} : f32x2{b4.z, b4.w};
+                    const f32x2 t0 = pk_fma(pk_add(pk_add(a0, a1), a2), inv2, bb);
+                    const f32x2 t1 = pk_fma(pk_sub(pk_sub(a1, a2), a3), inv2, bb);
                     if (add_res) {
-                        float r0 = res[nt][0][r], r1 = res[nt][1][r];
-                        asm("v_add_f32 %0, %0, %1\n\tv_med3_f32 %0, %0, 0, %2" : "+v"(r0) : "v"(t0), "v"(kWClamp));
-                        asm("v_add_f32 %0, %0, %1\n\tv_med3_f32 %0, %0, 0, %2" : "+v"(r1) : "v"(t1), "v"(kWClamp));
-                        res[nt][0][r] = r0;
-                        res[nt][1][r] = r1;
-                        v0[r] = r0;
-                        v1[r] = r1;
+                        // skip connection IN PLACE on the residual registers: left to the allocator, the new residual
+                        // went to a second register set and every layer paid 32-64 v_mov for the loop-carried values
+                        f32x2 r0 = whalf(res[nt][0], h), r1 = whalf(res[nt][1], h);
+                        pk_add_relu_inplace(r0, t0);
+                        pk_add_relu_inplace(r1, t1);
+                        wsethalf(res[nt][0], h, r0);
+                        wsethalf(res[nt][1], h, r1);
+                        v0[h] = r0;
+                        v1[h] = r1;
                     } else {
-                        v0[r] = __builtin_amdgcn_fmed3f(t0, 0.f, kWClamp);
-                        v1[r] = __builtin_amdgcn_fmed3f(t1, 0.f, kWClamp);
+                        v0[h] = f32x2{__builtin_amdgcn_fmed3f(t0.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t0.y, 0.f, kWClamp)};
+                        v1[h] = f32x2{__builtin_amdgcn_fmed3f(t1.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t1.y, 0.f, kWClamp)};
                     }
                 }
-                sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0]), __float_as_uint(v0[1])),
-                                             max(__float_as_uint(v0[2]), __float_as_uint(v0[3]))));
-                sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0]), __float_as_uint(v1[1])),
-                                             max(__float_as_uint(v1[2]), __float_as_uint(v1[3]))));
+                sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0].x), __float_as_uint(v0[0].y)),
+                                             max(__float_as_uint(v0[1].x), __float_as_uint(v0[1].y))));
+                sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0].x), __float_as_uint(v1[0].y)),
+                                             max(__float_as_uint(v1[1].x), __float_as_uint(v1[1].y))));
                 if (!last) {
-                    f32x4 V[4];
+                    f32x2 V[4][2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dl = quad_prev(v1[r]), dr = quad_next(v0[r]);   // in(2j-1), in(2j+2)
-                        V[0][r] = fmaf(dl, mask_l, -v1[r]);      // the board's edge: in(-1) = in(8) = 0
-                        V[1][r] = v0[r] + v1[r];
-                        V[2][r] = v1[r] - v0[r];
-                        V[3][r] = fmaf(-dr, mask_r, v0[r]);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 dl = {quad_prev(v1[h].x), quad_prev(v1[h].y)};   // in(2j-1)
+                        const f32x2 dr = {quad_next(v0[h].x), quad_next(v0[h].y)};   // in(2j+2)
+                        V[0][h] = pk_fma_nc(dl, mask_l2, v1[h]);     // dl * mask - v1; the board's edge: in(-1) = in(8) = 0
+                        V[1][h] = pk_add(v0[h], v1[h]);
+                        V[2][h] = pk_sub(v1[h], v0[h]);
+                        V[3][h] = pk_fma_na(dr, mask_r2, v0[h]);     // v0 - dr * mask
                     }
 #pragma unroll
                     for (int xi = 0; xi < 4; ++xi) {
                         uint2 hi, lo;
-                        hi.x = wpack(V[xi][0], V[xi][1]);
-                        hi.y = wpack(V[xi][2], V[xi][3]);
-                        lo.x = wresid(hi.x, V[xi][0], V[xi][1]);
-                        lo.y = wresid(hi.y, V[xi][2], V[xi][3]);
+                        hi.x = wpack(V[xi][0].x, V[xi][0].y);
+                        hi.y = wpack(V[xi][1].x, V[xi][1].y);
+                        lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
+                        lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
                         char* dst = lds + wr_off[nt] + xi * kWTile;
                         *(uint2*)dst = hi;
                         *(uint2*)(dst + 256) = lo;
@@ -412,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         // cycles + 2 LDS reads + address VALU ~ 48 of its 48 cycles), so the extra VALU is not hidden, it slows the
         // partner's convolution.  Tried again with the arithmetic at s_setprio 0 and the convolution at s_setprio 3, whole
         // and for one or two N-tiles only: 3.60 / 2.94 / 3.04 ms -- the 16-64 extra live VGPRs spill at the 256 limit.)
-        if (!last) {   // the first weight group of the next convolution: its L2 latency hides under the epilogue
+        if (layer == 0 && !last) {   // the first weight group of the first convolution; the later ones load theirs in
+                                     // the previous convolution's last group
 #pragma unroll
             for (int f = 0; f < 8; ++f) wq[0][f] = wl[(size_t)f * 64];
         }
@@ -429,6 +483,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         // ---------------- conv `layer+1` in the Winograd domain: 12 groups (row tap d, k-step kk) x 16 steps (N-tile,
         // xi) x 3 split products.  One straight-line software pipeline over all 192 steps: the two LDS reads of step
         // q+2 and, spread over a group, the eight weight loads of the next group sit between the MFMAs.
+        // (Tried with the 30 registers the leaner epilogue freed: LDS prefetch distance 3 and 4, and the two waves of a SIMD
+        // taking turns at s_setprio 2 group by group, to even out the oldest-first arbitration that lets one of them
+        // finish its convolution ~8 k cycles before the other: 2.561-2.578 vs 2.562 ms -- no change.)
         // step q = ((d*4 + kk)*4 + nt)*4 + xi.  (Tried: xi as the outer index of a group with ONE 8-fragment weight ring --
         // the pair of (group, xi) reloaded right after its fourth use -- and per-use address arithmetic instead of the
         // hoisted (key ^ k-step) values: 32 VGPRs fewer, no spill, but 2.88 vs 2.69 ms: the extra VALU per step costs more
@@ -476,7 +533,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                 // next group's fragments, one per step, as early as the ring allows (its other half is free from the
                 // group's first step on): at TP = 2 that is >= 8 steps = 770+ cycles of cover for the L2 latency (issued
                 // at steps 4..11 both waves of a SIMD stalled ~300 cycles at every group boundary)
-                if (grp < 11 && step >= OTH_WLD0 && step < OTH_WLD0 + 8)
+                // (grp = 11 loads group 0 of the NEXT convolution -- the layers are contiguous, and one zero group pads the
+                // end of the array for the last one: issued together before the barrier instead, the eight waves' 64 KB
+                // burst through the CU's one 64 B/clk vector-memory path held every wave for ~1.1 k cycles per layer)
+                if (grp == 10 && step == GS / 2) {
+                    b4n = *(const float4*)(a.bias + (layer + 1) * 128 + ch0);
+                    invn = a.inv[layer + 1];
+                }
+                if (step >= OTH_WLD0 && step < OTH_WLD0 + 8)
                     wq[(grp + 1) & 1][step - OTH_WLD0] =
                         wl[(size_t)(grp + 1) * (8 * 8 * 64) + (size_t)(step - OTH_WLD0) * 64];
                 OTH_WSB;
@@ -524,11 +588,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     const unsigned long long tpre_ = w_clk() - theads_;   // res -> LDS planes + barriers
     heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
                  logp + pos0 * 65, vout + pos0, hst_);
+#if OTH_STAMPS != 2   // -DOTH_STAMPS=2 keeps the layer phases (weight prefetch | barriers | epilogue | conv) instead
     if (a.dbg && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[3] = w_clk() - theads_;   // (overwrites the conv sum)
         o[0] = tpre_; o[1] = hst_[0]; o[2] = hst_[1];   // (overwrite prefetch / barriers / epilogue sums)
     }
+#endif
 #else
     heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
                  logp + pos0 * 65, vout + pos0);
@@ -567,7 +633,7 @@ int wino_pack_weights(oth_net* net) {
     net->wino = ww;
     const size_t frag = 64 * 8;                              // halfs per fragment
     const size_t layer_halfs = (size_t)12 * 8 * 8 * frag;    // 12 groups x 8 waves x (4 xi x hi/lo)
-    std::vector<uint16_t> w((size_t)L * layer_halfs), stem((size_t)8 * 2 * frag);
+    std::vector<uint16_t> w((size_t)L * layer_halfs + 8 * 8 * frag), stem((size_t)8 * 2 * frag);   // + one zero group: the last conv's look-ahead
     std::vector<float> bias((size_t)(L + 1) * 128), inv(L + 1);
     {   // stem: direct, gemm k = tap*3 + plane (27 of 32), rows = 16 channels of a wave
         const FoldedConv& cv = hn.stem;
@@ -694,8 +760,13 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
                 (double)(r1 - r0) * 1e-5);
         double pro = 0;
         for (size_t w = 0; w < (size_t)dbg_grid * 8; ++w) pro += (double)h[w * 8 + 7];
+#if OTH_STAMPS == 2
+        fprintf(stderr, "[wino stamps] per-wave cycles: weight prefetch %.0f | barrier waits %.0f | epilogues %.0f | convolutions %.0f | layers total %.0f | prologue+stem %.0f\n",
+                sm[0] / nw * 2, sm[1] / nw * 2, sm[2] / nw * 2, sm[3] / nw * 2, sm[4] / nw * 2, pro / nw * 2);
+#else
         fprintf(stderr, "[wino stamps] per-wave cycles (x2: averaged over twice the workgroups): planes->LDS %.0f | heads stage 1 (1x1 convs) %.0f | FCs %.0f | heads all %.0f | layers total %.0f | prologue+stem %.0f\n",
                 sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, pro / nw);
+#endif
         (void)hipFree(a.dbg);
     }
 #endif
