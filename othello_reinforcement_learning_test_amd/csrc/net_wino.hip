@@ -29,6 +29,7 @@
 
 #include "net.h"
 #include "net_heads.h"
+#include "net_epilogue.h"
 
 namespace oth {
 
@@ -107,62 +108,6 @@ __device__ __forceinline__ float quad_prev(float v) {
 }
 __device__ __forceinline__ float quad_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF9, 0xf, 0xf, true));  // [1,2,3,3]
-}
-
-// two fp32 values -> packed f16 (round to nearest even)
-__device__ __forceinline__ uint32_t wpack(float a, float b) {
-    using half2v = _Float16 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, half2v{(_Float16)a, (_Float16)b});
-}
-// packed f16 of (a - hi.lo, b - hi.hi): the low parts of the operand split.  The fp32 difference is exact (hi is a
-// rounded to 11 bits), so the only rounding is the final one to f16 -- the same value as converting hi back, subtracting
-// and converting again, in two instructions.
-__device__ __forceinline__ uint32_t wresid(uint32_t hi, float a, float b) {
-    uint32_t lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
-    return lo;
-}
-
-using f32x2 = float __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 whalf(const f32x4& v, int h) { return h == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}; }
-__device__ __forceinline__ void wsethalf(f32x4& v, int h, f32x2 x) {
-    v[2 * h] = x.x;
-    v[2 * h + 1] = x.y;
-}
-// packed fp32 (two independent IEEE operations per instruction: the results are those of the scalar forms)
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {   // a - b
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma_nc(f32x2 a, f32x2 b, f32x2 c) {   // a * b - c
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma_na(f32x2 a, f32x2 b, f32x2 c) {   // c - a * b
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-__device__ __forceinline__ void pk_add_relu_inplace(f32x2& r, f32x2 t) {   // r = clamp(r + t, 0, kWClamp) in r's registers
-    asm("v_pk_add_f32 %0, %0, %1" : "+v"(r) : "v"(t));
-    float x = r.x, y = r.y;
-    asm("v_med3_f32 %0, %0, 0, %1" : "+v"(x) : "v"(kWClamp));
-    asm("v_med3_f32 %0, %0, 0, %1" : "+v"(y) : "v"(kWClamp));
-    r = f32x2{x, y};
 }
 
 #define OTH_WSB __builtin_amdgcn_sched_barrier(0)
@@ -416,8 +361,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                         // skip connection IN PLACE on the residual registers: left to the allocator, the new residual
                         // went to a second register set and every layer paid 32-64 v_mov for the loop-carried values
                         f32x2 r0 = whalf(res[nt][0], h), r1 = whalf(res[nt][1], h);
-                        pk_add_relu_inplace(r0, t0);
-                        pk_add_relu_inplace(r1, t1);
+                        pk_add_relu_inplace(r0, t0, kWClamp);
+                        pk_add_relu_inplace(r1, t1, kWClamp);
                         wsethalf(res[nt][0], h, r0);
                         wsethalf(res[nt][1], h, r1);
                         v0[h] = r0;
@@ -427,10 +372,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                         v1[h] = f32x2{__builtin_amdgcn_fmed3f(t1.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t1.y, 0.f, kWClamp)};
                     }
                 }
+#ifndef OTH_ABL_NOSAT
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0].x), __float_as_uint(v0[0].y)),
                                              max(__float_as_uint(v0[1].x), __float_as_uint(v0[1].y))));
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0].x), __float_as_uint(v1[0].y)),
                                              max(__float_as_uint(v1[1].x), __float_as_uint(v1[1].y))));
+#endif
                 if (!last) {
                     f32x2 V[4][2];
 #pragma unroll
@@ -450,8 +397,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                         lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
                         lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
                         char* dst = lds + wr_off[nt] + xi * kWTile;
+#ifdef OTH_ABL_NOWRITE   // timing ablation only (wrong results): no V stores; the values stay live through a dummy use
+                        asm volatile("" :: "v"(hi), "v"(lo), "v"(dst));
+#else
                         *(uint2*)dst = hi;
                         *(uint2*)(dst + 256) = lo;
+#endif
                     }
                 }
                 OTH_WSB;   // one N-tile at a time
@@ -525,11 +476,19 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                 if (q < GS) acc[xi][nt] = wmfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = wmfma(wh, xl[sl], acc[xi][nt]);
                 OTH_WSB;
+#ifdef OTH_ABL_HALFLDS   // timing ablation only (wrong results): every second step reuses stale operand registers
+                if (q + PD < QT && ((q + PD) & 1) == 0) xh[psl] = *(const half8*)src_of(q + PD);
+#else
                 if (q + PD < QT) xh[psl] = *(const half8*)src_of(q + PD);
+#endif
                 OTH_WSB;
                 acc[xi][nt] = wmfma(wh, xh[sl], acc[xi][nt]);
                 OTH_WSB;
+#ifdef OTH_ABL_HALFLDS
+                if (q + PD < QT && ((q + PD) & 1) == 0) xl[psl] = *(const half8*)(src_of(q + PD) + 256);
+#else
                 if (q + PD < QT) xl[psl] = *(const half8*)(src_of(q + PD) + 256);
+#endif
                 // next group's fragments, one per step, as early as the ring allows (its other half is free from the
                 // group's first step on): at TP = 2 that is >= 8 steps = 770+ cycles of cover for the L2 latency (issued
                 // at steps 4..11 both waves of a SIMD stalled ~300 cycles at every group boundary)
