@@ -59,6 +59,7 @@ struct H3Args {
     const float* pfc_wt;
     const float* vfc1_wt;
     int* sat;   // set to 1 when an activation reaches the clamp (oth_net_saturated)
+    unsigned long long* dbg;   // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
 
 template <int F, int BS, int P>
@@ -80,7 +81,7 @@ struct H3Geom {
     static_assert(2 * BS <= 16, "the inter-position gap must hold two zero rows");
     static constexpr int HI_BYTES = NKC * NC * 16;    // size of the hi array (= offset of the lo array)
     static constexpr int ACT_BYTES = 2 * HI_BYTES;
-    static constexpr int SCRATCH_BYTES = 192 * 4;     // heads
+    static constexpr int SCRATCH_BYTES = 192 * 4 * P; // heads: 192 floats per position
     static constexpr int WAVE_BYTES = ACT_BYTES + SCRATCH_BYTES;
     static_assert(F * NCO * 4 <= ACT_BYTES, "the fp32 planes of the heads alias the activation arrays");
 };
@@ -97,6 +98,26 @@ __device__ __forceinline__ f32x4 mfma_h(half8 a, half8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 }
+
+#ifdef OTH_STAMPS
+__device__ __forceinline__ unsigned long long h3_clk() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ unsigned long long h3_realclk() {   // 100 MHz constant clock
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define OTH_HSTAMP(i) { const unsigned long long t1_ = h3_clk(); ph_[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define OTH_HSTAMP(i)
+#endif
 
 // SHARE: the WPB waves of a workgroup run the SAME weight stream on different positions.  Unshared, every wave pulls all
 // NB*2 KB of a (k-step, tap) step from L2 itself (at 64 filters that is 8 KB per 60-84 MFMAs per wave: ~16 TB/s of L2 -> CU
@@ -120,6 +141,10 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         const int64_t k = *n_valid;
         nv = k < n ? k : n;
     }
+#ifdef OTH_STAMPS
+    unsigned long long ph_[5] = {0, 0, 0, 0, 0}, t0_ = h3_clk();   // prologue | weight wait + conv | epilogue | planes | heads
+    const unsigned long long tstart_ = t0_, rstart_ = h3_realclk();
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pos0 = ((int64_t)blockIdx.x * WPB + wave) * P;
     if (SHARE ? (int64_t)blockIdx.x * WPB * P >= nv : pos0 >= nv) return;   // unshared waves are independent
@@ -198,6 +223,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 #pragma unroll
         for (int f = 0; f < NB * 2; ++f) wq[f] = ring[f * 64 + lane];
     }
+    OTH_HSTAMP(0)
     for (int layer = 0; layer < a.n_layers; ++layer) {
         const int KK = layer == 0 ? 1 : F / 32;   // k-steps of 32 input channels (stem: planes 0..2 of chunk 0)
         const int nsteps = 9 * KK;
@@ -286,6 +312,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                 }
             }
         }
+        OTH_HSTAMP(1)
         // ---- epilogue: undo the weight scale, bias, skip connection (net.py:58-59), ReLU, re-split, rewrite in place.
         //      add_res / set_res are compile-time flags of three instantiations (no v_cndmask per value).
         const float inv = a.inv[layer];
@@ -343,6 +370,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                 OTH_PIN_ACC(acc[b][t]);
             }
         OTH_PIN_ACC_END();
+        OTH_HSTAMP(2)
     }
 #undef OTH_SB
 
@@ -359,12 +387,31 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 #pragma unroll
                 for (int r = 0; r < 4; ++r) planes[(b * 16 + 4 * g4 + r) * NCO + ci] = res[b][t][r] * (1.0f / kH3ActScale);
             }
-    for (int p = 0; p < P; ++p) {
-        if (pos0 + p >= nv) break;
+    OTH_HSTAMP(3)
+    {   // all P positions of the wave at once (shared FC weight loads); dead positions compute on zero planes, unstored
         const int c = lane < CELLS ? lane : 0;
-        heads_wave<F, BS>(a.heads, a.pfc_wt, a.vfc1_wt, planes + p * CELLS + c, NCO, scratch, lane,
-                          logp + (pos0 + p) * NP, vout + pos0 + p);
+        const float* srcs[P];
+        float* lps[P];
+        float* vs[P];
+        bool live[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            srcs[p] = planes + p * CELLS + c;
+            lps[p] = logp + (pos0 + p) * NP;
+            vs[p] = vout + pos0 + p;
+            live[p] = pos0 + p < nv;
+        }
+        heads_wave_n<F, BS, P>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
     }
+#ifdef OTH_STAMPS
+    OTH_HSTAMP(4)
+    if (a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * WPB + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ph_[i];
+        o[5] = h3_clk() - tstart_;
+        o[6] = h3_realclk() - rstart_;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -470,6 +517,29 @@ static int launch_h3(oth_net* net, const H3Args& a, const uint64_t* sb, const ui
     }
     const int64_t per_block = (int64_t)P * WPB;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+#ifdef OTH_STAMPS
+    H3Args ad = a;
+    OTH_HIP(hipMalloc(&ad.dbg, (size_t)grid * WPB * 8 * sizeof(unsigned long long)));
+    OTH_HIP(hipMemset(ad.dbg, 0, (size_t)grid * WPB * 8 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB, SHARE>), dim3(grid), dim3(64 * WPB), lds, stream, ad, sb, ob, lg, n, n_valid,
+                       logp, v);
+    OTH_HIP(hipStreamSynchronize(stream));
+    {
+        std::vector<unsigned long long> h((size_t)grid * WPB * 8);
+        OTH_HIP(hipMemcpy(h.data(), ad.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double sm[7] = {0, 0, 0, 0, 0, 0, 0};
+        size_t nw = 0;
+        for (size_t w = 0; w < (size_t)grid * WPB; ++w) {
+            if (!h[w * 8 + 5]) continue;
+            ++nw;
+            for (int i = 0; i < 7; ++i) sm[i] += (double)h[w * 8 + i];
+        }
+        fprintf(stderr, "[h3 stamps %dx%d P%d] per-wave cycles: prologue %.0f | weight wait + conv %.0f | epilogues %.0f | planes %.0f | heads %.0f | total %.0f | clock %.3f GHz\n",
+                F, BS, P, sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, sm[5] / nw, sm[5] / sm[6] * 0.1);
+        (void)hipFree(ad.dbg);
+    }
+    return OTH_OK;
+#endif
     hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB, SHARE>), dim3(grid), dim3(64 * WPB), lds, stream, a, sb, ob, lg, n, n_valid,
                        logp, v);
     OTH_HIP(hipGetLastError());

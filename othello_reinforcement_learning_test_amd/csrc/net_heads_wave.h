@@ -16,58 +16,145 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// `src` = address of channel 0 of THIS LANE's cell (lane = cell index; lanes >= BS*BS pass any valid cell), channel ch
-// at src[ch * plane_stride]; scratch: 192 floats of LDS private to the wave; pfc_wt / vfc1_wt: FC weights transposed
-// on the host ([2*cells][cells+1], [cells][256]) so that lanes read consecutive outputs.
+// `src[p]` = address of channel 0 of THIS LANE's cell of position p (lane = cell index; lanes >= BS*BS pass any valid
+// cell), channel ch at src[p][ch * plane_stride]; scratch: 192 * P floats of LDS private to the wave; pfc_wt / vfc1_wt: FC
+// weights transposed on the host ([2*cells][cells+1], [cells][256]) so that lanes read consecutive outputs.
+//
+// P positions at once: every FC weight is loaded once and used for all of them, and the loops run in batches of U
+// independent loads (U = 16, or 12 where the trip count asks for it) followed by their FMAs.  The first version took
+// one position at a time with rolled loops -- one L2 round trip per iteration, and on 8x8 the 65th policy output was a
+// 128-iteration loop on lane 0 alone -- and cost 42-55 k cycles per position: 30 % of the 5x64 kernel on 6x6, 48 % of
+// the 2x32 kernel (in-kernel stamps, round 3).
+template <int F, int BS, int P>
+__device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* __restrict__ pfc_wt,
+                                             const float* __restrict__ vfc1_wt, const float* const (&src)[P],
+                                             int plane_stride, float* scratch, int lane, float* const (&lp)[P],
+                                             float* const (&vout)[P], const bool (&live)[P]) {
+    constexpr int CELLS = BS * BS, NP = CELLS + 1, NI = 2 * CELLS;
+    constexpr int U1 = 16;                                  // channels per batch (F is a multiple of 16)
+    constexpr int U2 = NI % 16 == 0 ? 16 : 12;              // policy FC inputs per batch (72 = 6 x 12, 128 = 8 x 16)
+    constexpr int U3 = CELLS % 16 == 0 ? 8 : 6;             // value FC1 inputs per batch (x 4 outputs per lane)
+    static_assert(F % U1 == 0 && NI % U2 == 0 && CELLS % U3 == 0, "batch sizes must divide the trip counts");
+    static_assert(NP <= 65, "one policy output per lane, plus at most one more");
+    {   // 1x1 convs (+ folded BN) + ReLU: lane = cell
+        float a0[P], a1[P], av[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) a0[p] = a1[p] = av[p] = 0.f;
+#pragma unroll 1   // a batch is the unit: unrolled further, hipcc hoists every load and spills
+        for (int c0 = 0; c0 < F; c0 += U1) {
+            float x[P][U1];
+#pragma unroll
+            for (int u = 0; u < U1; ++u)
+#pragma unroll
+                for (int p = 0; p < P; ++p) x[p][u] = src[p][(c0 + u) * plane_stride];
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                const float w0 = hp.pconv_w[(c0 + u) * 2 + 0], w1 = hp.pconv_w[(c0 + u) * 2 + 1], wv = hp.vconv_w[c0 + u];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    a0[p] = fmaf(x[p][u], w0, a0[p]);
+                    a1[p] = fmaf(x[p][u], w1, a1[p]);
+                    av[p] = fmaf(x[p][u], wv, av[p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            scratch[p * 192 + lane] = fmaxf(a0[p] + hp.pconv_b[0], 0.f);        // flatten order (channel, cell): net.py:88
+            scratch[p * 192 + 64 + lane] = fmaxf(a1[p] + hp.pconv_b[1], 0.f);
+            scratch[p * 192 + 128 + lane] = fmaxf(av[p] + hp.vconv_b[0], 0.f);
+        }
+    }
+    // policy FC: lane = output (lanes >= NP idle); the 65th output of an 8x8 board is a wave reduction over the inputs
+    const int ol = lane < NP ? lane : 0;
+    float s0[P], sx[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s0[p] = hp.pfc_b[ol];
+        sx[p] = 0.f;
+    }
+#pragma unroll 1   // a batch is the unit: unrolled further, hipcc hoists every load and spills
+    for (int i0 = 0; i0 < NI; i0 += U2) {
+        float w[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) w[u] = pfc_wt[(size_t)(i0 + u) * NP + ol];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int i = i0 + u;   // rolled outer loop: the feature index is formed at run time
+            const int fi = (i / CELLS) * 64 + (i % CELLS);
+#pragma unroll
+            for (int p = 0; p < P; ++p) s0[p] = fmaf(w[u], scratch[p * 192 + fi], s0[p]);
+        }
+    }
+    if constexpr (NP > 64) {
+#pragma unroll
+        for (int k = 0; k < (NI + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            if (i < NI) {
+                const float w = pfc_wt[(size_t)i * NP + 64];
+                const int fi = (i / CELLS) * 64 + (i % CELLS);
+#pragma unroll
+                for (int p = 0; p < P; ++p) sx[p] = fmaf(w, scratch[p * 192 + fi], sx[p]);
+            }
+        }
+    }
+    // value FC1 (256 outputs: 4 per lane)
+    float h[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[p][j] = hp.vfc1_b[lane + 64 * j];
+#pragma unroll 1   // a batch is the unit: unrolled further, hipcc hoists every load and spills
+    for (int i0 = 0; i0 < CELLS; i0 += U3) {
+        float w[U3][4];
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[u][j] = vfc1_wt[(size_t)(i0 + u) * 256 + lane + 64 * j];
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float x = scratch[p * 192 + 128 + i0 + u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[p][j] = fmaf(w[u][j], x, h[p][j]);
+            }
+    }
+    float w2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2[j] = hp.vfc2_w[lane + 64 * j];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        // log_softmax over the NP logits, FC2 + tanh
+        const float l0 = lane < NP ? s0[p] : -INFINITY;
+        float l64 = -INFINITY;
+        if constexpr (NP > 64) l64 = wave_sum(sx[p]) + hp.pfc_b[64];
+        const float m = fmaxf(wave_max(l0), l64);
+        float e = lane < NP ? expf(l0 - m) : 0.f;
+        if (NP > 64 && lane == 0) e += expf(l64 - m);
+        const float lse = logf(wave_sum(e));
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part = fmaf(w2[j], fmaxf(h[p][j], 0.f), part);
+        const float tot = wave_sum(part);
+        if (live[p]) {
+            if (lane < NP && lane < 64) lp[p][lane] = l0 - m - lse;
+            if (NP > 64 && lane == 0) lp[p][64] = l64 - m - lse;
+            if (lane == 0) *vout[p] = tanhf(tot + hp.vfc2_b[0]);
+        }
+    }
+}
+
+// one position (net_f32.hip)
 template <int F, int BS>
 __device__ __forceinline__ void heads_wave(const HeadParams& hp, const float* __restrict__ pfc_wt,
                                            const float* __restrict__ vfc1_wt, const float* src, int plane_stride,
                                            float* scratch, int lane, float* __restrict__ lp, float* __restrict__ vout) {
-    constexpr int CELLS = BS * BS, NP = CELLS + 1;
-    {   // 1x1 convs (+ folded BN) + ReLU: lane = cell
-        float a0 = 0.f, a1 = 0.f, av = 0.f;
-        for (int ch = 0; ch < F; ++ch) {
-            const float x = src[ch * plane_stride];
-            a0 = fmaf(x, hp.pconv_w[ch * 2 + 0], a0);
-            a1 = fmaf(x, hp.pconv_w[ch * 2 + 1], a1);
-            av = fmaf(x, hp.vconv_w[ch], av);
-        }
-        scratch[lane] = fmaxf(a0 + hp.pconv_b[0], 0.f);        // flatten order (channel, cell): net.py:88
-        scratch[64 + lane] = fmaxf(a1 + hp.pconv_b[1], 0.f);
-        scratch[128 + lane] = fmaxf(av + hp.vconv_b[0], 0.f);
-    }
-    // policy FC + log_softmax: lane handles outputs lane and lane + 64
-    float l0 = -INFINITY, l1 = -INFINITY;
-    {
-        float s0 = lane < NP ? hp.pfc_b[lane] : 0.f;
-        float s1 = lane + 64 < NP ? hp.pfc_b[lane + 64] : 0.f;
-        for (int i = 0; i < 2 * CELLS; ++i) {
-            const float x = scratch[(i / CELLS) * 64 + (i % CELLS)];
-            if (lane < NP) s0 = fmaf(pfc_wt[(size_t)i * NP + lane], x, s0);
-            if (lane + 64 < NP) s1 = fmaf(pfc_wt[(size_t)i * NP + lane + 64], x, s1);
-        }
-        if (lane < NP) l0 = s0;
-        if (lane + 64 < NP) l1 = s1;
-    }
-    const float m = wave_max(fmaxf(l0, l1));
-    const float se = wave_sum((lane < NP ? expf(l0 - m) : 0.f) + (lane + 64 < NP ? expf(l1 - m) : 0.f));
-    const float lse = logf(se);
-    if (lane < NP) lp[lane] = l0 - m - lse;
-    if (lane + 64 < NP) lp[lane + 64] = l1 - m - lse;
-    // value FC1 (256 outputs: 4 per lane) + ReLU + FC2 + tanh
-    float h[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = hp.vfc1_b[lane + 64 * j];
-    for (int i = 0; i < CELLS; ++i) {
-        const float x = scratch[128 + i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = fmaf(vfc1_wt[(size_t)i * 256 + lane + 64 * j], x, h[j]);
-    }
-    float part = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part = fmaf(hp.vfc2_w[lane + 64 * j], fmaxf(h[j], 0.f), part);
-    const float tot = wave_sum(part);
-    if (lane == 0) *vout = tanhf(tot + hp.vfc2_b[0]);
+    const float* const srcs[1] = {src};
+    float* const lps[1] = {lp};
+    float* const vs[1] = {vout};
+    const bool live[1] = {true};
+    heads_wave_n<F, BS, 1>(hp, pfc_wt, vfc1_wt, srcs, plane_stride, scratch, lane, lps, vs, live);
 }
 
 }  // namespace oth
