@@ -68,7 +68,7 @@ struct TrunkGeom {
     static constexpr int NPL = F < 4 ? 4 : F;       // planes (the stem reads 4: self, opp, legal, zero)
     static constexpr int NW = 9 * NB;               // weight values per lane per k-step
     static constexpr int NCH = (NW + 3) / 4;        // 16-byte chunks per lane per k-step
-    static constexpr int SCRATCH = 192;             // head scratch (words): pf0[64] pf1[64] vf[64]
+    static constexpr int SCRATCH = 192 * P;         // head scratch (words) per position: pf0[64] pf1[64] vf[64]
     static constexpr int WAVE_WORDS = NPL * PS + SCRATCH;
 };
 
@@ -136,6 +136,13 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_f32(F32Args a, const uint64_
         float4 wq[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) wq[c] = wl[(size_t)c * 64];
+        float4 bias_q[NB];   // the epilogue's biases, requested before the convolution (one wave per SIMD: a load inside
+                             // the epilogue is a bare L2 round trip per row block)
+        constexpr bool PREB = NB <= 4;   // at 128 filters the 32 extra live registers cost more than the wait (-4.5 %)
+        if constexpr (PREB) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bias_q[b] = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * kg);
+        }
         for (int kc = 0; kc < KC; ++kc) {
             float w[NCH * 4];
 #pragma unroll
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_f32(F32Args a, const uint64_
         const bool set_res = layer == 0 || add_res;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float4 bias = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * kg);
+            const float4 bias = PREB ? bias_q[b] : *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * kg);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 f32x4 v = acc[b][t];
@@ -184,12 +191,21 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_f32(F32Args a, const uint64_
         }
     }
 
-    // ---- heads (net.py:62-136), one position at a time, whole wave
-    for (int p = 0; p < P; ++p) {
-        if (pos0 + p >= nv) break;
+    // ---- heads (net.py:62-136): whole wave, all P positions at once (shared FC weight loads); dead positions unstored
+    {
         const int c = lane < CELLS ? lane : 0;
-        heads_wave<F, BS>(a.heads, a.pfc_wt, a.vfc1_wt, act + p * POSW + (c / BS + 1) * PW + (c % BS + 1), PS, scratch, lane,
-                          logp + (pos0 + p) * NP, vout + pos0 + p);
+        const float* srcs[P];
+        float* lps[P];
+        float* vs[P];
+        bool live[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            srcs[p] = act + p * POSW + (c / BS + 1) * PW + (c % BS + 1);
+            lps[p] = logp + (pos0 + p) * NP;
+            vs[p] = vout + pos0 + p;
+            live[p] = pos0 + p < nv;
+        }
+        heads_wave_n<F, BS, P>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, PS, scratch, lane, lps, vs, live);
     }
 }
 

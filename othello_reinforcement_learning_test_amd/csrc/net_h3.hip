@@ -228,6 +228,13 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         const int KK = layer == 0 ? 1 : F / 32;   // k-steps of 32 input channels (stem: planes 0..2 of chunk 0)
         const int nsteps = 9 * KK;
         const uint4* wl = a.w + a.layer_off[layer] + lane;   // + (step * NB * 2 + frag) * 64
+        // bias and scale of this layer's epilogue, requested before the convolution: loaded inside the epilogue, each row
+        // block waited ~700 cycles for its own L2 round trip with nothing else to run (one wave per SIMD) -- 2.8 k of
+        // the epilogue's 3.8 k cycles per layer (in-kernel stamps)
+        float4 bias_q[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bias_q[b] = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * g4);
+        const float inv = a.inv[layer];
         if constexpr (!SHARE) {
 #pragma unroll
             for (int f = 0; f < NB * 2; ++f) wq[f] = wl[(size_t)f * 64];
@@ -315,13 +322,12 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         OTH_HSTAMP(1)
         // ---- epilogue: undo the weight scale, bias, skip connection (net.py:58-59), ReLU, re-split, rewrite in place.
         //      add_res / set_res are compile-time flags of three instantiations (no v_cndmask per value).
-        const float inv = a.inv[layer];
         auto epilogue = [&](auto ADD, auto SET) {
             constexpr bool add_res = decltype(ADD)::value;   // second conv of a block
             constexpr bool set_res = decltype(SET)::value;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float4 bias = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * g4);
+                const float4 bias = bias_q[b];
                 const f32x2 bias01 = {bias.x, bias.y}, bias23 = {bias.z, bias.w}, inv2 = {inv, inv};
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
