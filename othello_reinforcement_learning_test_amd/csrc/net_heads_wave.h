@@ -21,7 +21,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // weights transposed on the host ([2*cells][cells+1], [cells][256]) so that lanes read consecutive outputs.
 //
 // P positions at once: every FC weight is loaded once and used for all of them, and the loops run in batches of U
-// independent loads (U = 16, or 12 where the trip count asks for it) followed by their FMAs.  The first version took
+// independent loads (16, or 12 where the trip count asks for it) followed by their FMAs, one accumulator per position.  The first version took
 // one position at a time with rolled loops -- one L2 round trip per iteration, and on 8x8 the 65th policy output was a
 // 128-iteration loop on lane 0 alone -- and cost 42-55 k cycles per position: 30 % of the 5x64 kernel on 6x6, 48 % of
 // the 2x32 kernel (in-kernel stamps, round 3).
@@ -33,9 +33,11 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
     constexpr int CELLS = BS * BS, NP = CELLS + 1, NI = 2 * CELLS;
     constexpr int U1 = 16;                                  // channels per batch (F is a multiple of 16)
     constexpr int U2 = NI % 16 == 0 ? 16 : 12;              // policy FC inputs per batch (72 = 6 x 12, 128 = 8 x 16)
-    constexpr int U3 = CELLS % 16 == 0 ? 8 : 6;             // value FC1 inputs per batch (x 4 outputs per lane)
-    static_assert(F % U1 == 0 && NI % U2 == 0 && CELLS % U3 == 0, "batch sizes must divide the trip counts");
+    static_assert(F % U1 == 0 && NI % U2 == 0, "batch sizes must divide the trip counts");
     static_assert(NP <= 65, "one policy output per lane, plus at most one more");
+#ifdef OTH_HEADS_CHECK
+    float keep_v[P], keep_p[P];
+#endif
     {   // 1x1 convs (+ folded BN) + ReLU: lane = cell
         float a0[P], a1[P], av[P];
 #pragma unroll
@@ -63,6 +65,10 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
             scratch[p * 192 + lane] = fmaxf(a0[p] + hp.pconv_b[0], 0.f);        // flatten order (channel, cell): net.py:88
             scratch[p * 192 + 64 + lane] = fmaxf(a1[p] + hp.pconv_b[1], 0.f);
             scratch[p * 192 + 128 + lane] = fmaxf(av[p] + hp.vconv_b[0], 0.f);
+#ifdef OTH_HEADS_CHECK
+            keep_v[p] = fmaxf(av[p] + hp.vconv_b[0], 0.f);
+            keep_p[p] = fmaxf(a0[p] + hp.pconv_b[0], 0.f);
+#endif
         }
     }
     // policy FC: lane = output (lanes >= NP idle); the 65th output of an 8x8 board is a wave reduction over the inputs
@@ -101,24 +107,36 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
     // value FC1 (256 outputs: 4 per lane)
     float h[P][4];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int p = 0; p < P; ++p) h[p][0] = h[p][1] = h[p][2] = h[p][3] = 0.f;
+    // One output column per pass (j), batches of U2 rows -- the shape of the policy FC above.  (A batch of U3 rows x 4
+    // columns, i.e. 32 loads in flight feeding v_pk_fma_f32 pairs, gave wrong value outputs at ~1 % of the positions in
+    // ONE instantiation -- 32 filters on 8x8 -- and only with two workgroups resident per CU: bitwise-stable policy
+    // outputs, scratch verified intact, full vmcnt(0) waits no cure, the rolled loop correct.  Not understood; this form
+    // measures the same speed and is correct everywhere: tools/probes/diag_v2.py.)
+    constexpr int U4 = CELLS % 16 == 0 ? 16 : 12;
+    static_assert(CELLS % U4 == 0, "batch size must divide the trip count");
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        float hj[P];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[p][j] = hp.vfc1_b[lane + 64 * j];
-#pragma unroll 1   // a batch is the unit: unrolled further, hipcc hoists every load and spills
-    for (int i0 = 0; i0 < CELLS; i0 += U3) {
-        float w[U3][4];
+        for (int p = 0; p < P; ++p) hj[p] = hp.vfc1_b[lane + 64 * j];
+#pragma unroll 1
+        for (int i0 = 0; i0 < CELLS; i0 += U4) {
+            float w[U4];
 #pragma unroll
-        for (int u = 0; u < U3; ++u)
+            for (int u = 0; u < U4; ++u) w[u] = vfc1_wt[(size_t)(i0 + u) * 256 + lane + 64 * j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[u][j] = vfc1_wt[(size_t)(i0 + u) * 256 + lane + 64 * j];
+            for (int u = 0; u < U4; ++u)
 #pragma unroll
-        for (int u = 0; u < U3; ++u)
+                for (int p = 0; p < P; ++p) hj[p] = fmaf(w[u], scratch[p * 192 + 128 + i0 + u], hj[p]);
+        }
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float x = scratch[p * 192 + 128 + i0 + u];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[p][j] = fmaf(w[u][j], x, h[p][j]);
-            }
+        for (int p = 0; p < P; ++p) {   // h[p][j] with a run-time j: select, do not index (an indexed array goes to scratch memory)
+            h[p][0] = j == 0 ? hj[p] : h[p][0];
+            h[p][1] = j == 1 ? hj[p] : h[p][1];
+            h[p][2] = j == 2 ? hj[p] : h[p][2];
+            h[p][3] = j == 3 ? hj[p] : h[p][3];
+        }
     }
     float w2[4];
 #pragma unroll
@@ -140,7 +158,15 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
         if (live[p]) {
             if (lane < NP && lane < 64) lp[p][lane] = l0 - m - lse;
             if (NP > 64 && lane == 0) lp[p][64] = l64 - m - lse;
+#ifdef OTH_HEADS_CHECK
+            {   // diagnostic: has this wave's scratch changed since it was written?
+                const bool bv = scratch[p * 192 + 128 + lane] != keep_v[p], bp = scratch[p * 192 + lane] != keep_p[p];
+                const unsigned long long mv = __ballot(bv), mp = __ballot(bp);
+                if (lane == 0) *vout[p] = (mv || mp) ? 100.f + (mv ? 1.f : 0.f) + (mp ? 2.f : 0.f) : tanhf(tot + hp.vfc2_b[0]);
+            }
+#else
             if (lane == 0) *vout[p] = tanhf(tot + hp.vfc2_b[0]);
+#endif
         }
     }
 }

@@ -358,6 +358,34 @@ def test_wave_trunks_ragged_batches(pkg, nb, nf, bs, prec):
     assert bool((logp2[nvalid:] == 7.0).all()) and bool((v2[nvalid:] == 7.0).all())
 
 
+@pytest.mark.parametrize("nb,nf,bs,prec", [(2, 32, 8, "f16x3"), (2, 32, 6, "f16x3"), (5, 64, 8, "f16x3"), (5, 64, 6, "f16x3"),
+                                           (2, 16, 8, "f32"), (2, 16, 6, "f32"), (2, 128, 6, "f16x3")])
+def test_wave_trunks_full_occupancy_reproducible(pkg, nb, nf, bs, prec):
+    """4096 positions per launch -- several workgroups resident per CU -- five times over: every output bit-identical from
+    launch to launch and within 1e-4 of torch fp32.  (Round 3: a batched form of the value head's first FC gave wrong
+    values at ~1 % of the positions of the 32-filter 8x8 kernel, only with two workgroups per CU and differently in every
+    launch; smaller batches and a single launch compared at 1e-4 on 3000 positions did not catch it.)"""
+    torch.manual_seed(42)
+    net = pkg.OthelloResNet(nb, nf, board_size=bs).eval()
+    rng = np.random.Generator(np.random.PCG64(11))
+    n = 4096
+    occ = rng.random((n, bs, bs)) < 0.5
+    own = occ & (rng.random((n, bs, bs)) < 0.5)
+    x = torch.from_numpy(np.stack([own, occ & ~own, (~occ) & (rng.random((n, bs, bs)) < 0.4)], 1).astype(np.float32)).cuda()
+    with torch.no_grad():
+        rl, rv = net.cuda()(x)
+    ev = pkg.HipResNetEvaluator(net.cpu(), precision=prec)
+    logp0, v0 = ev.forward_planes(x)
+    torch.cuda.synchronize()
+    logp0, v0 = logp0.clone(), v0.clone()
+    assert (logp0 - rl).abs().max().item() < 1e-4 and (v0 - rv).abs().max().item() < 1e-4
+    for _ in range(4):
+        logp, v = ev.forward_planes(x)
+        torch.cuda.synchronize()
+        assert torch.equal(logp, logp0), "policy outputs differ between launches"
+        assert torch.equal(v, v0), ("value outputs differ between launches", int((v != v0).sum().item()))
+
+
 def test_net_large_batch_and_ragged_tail(pkg):
     """4096+3 real positions on the 10x128 network: fp32-equivalent MFMA trunk vs torch fp32 on the
     same weights (tolerance 1e-4), every row; batch sizes that are not a multiple of the tile."""

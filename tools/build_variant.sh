@@ -10,7 +10,7 @@ out=$root/build/$name
 mkdir -p "$out"
 make -s -j4 -C "$csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
-for f in net_mfma net_h3 net_wino; do
+for f in net_mfma net_h3 net_wino; do  # (heads experiments: net_h3 includes net_heads_wave.h)
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$csrc/$f.hip" -o "$out/$f.o" &
 done
 wait
