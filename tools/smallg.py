@@ -1,5 +1,5 @@
 """Small-engine rate (the reference's own kind of configuration: few parallel games, few simulations) without the
-timing hooks.  usage: smallg.py [sims]"""
+timing hooks.  usage: smallg.py [sims] [G,G,...]"""
 import sys
 import time
 
@@ -13,7 +13,8 @@ sims = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 torch.manual_seed(42)
 net = pkg.OthelloResNet(10, 128).eval()
 ev = pkg.HipResNetEvaluator(net)
-for G in (1, 8, 32, 256):
+Gs = tuple(int(t) for t in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 8, 32, 256)
+for G in Gs:
     eng = pkg.SearchEngine(G, sims, temperature_threshold=15, evaluator=ev)
     with torch.cuda.stream(torch.cuda.Stream()):
         eng.selfplay_run(G, 1, True)
