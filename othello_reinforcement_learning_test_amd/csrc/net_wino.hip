@@ -320,7 +320,16 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
 
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
-    uint4 wq[2][8];   // weight ring: [group parity][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments
+    // weight ring: [group mod RING][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments.  Two groups at TP = 2; FOUR
+    // at TP = 1, where the launch is one position per CU and bound by how many bytes of the weight stream (15.7 MB per
+    // forward through ONE CU's vector-memory path), not by MFMAs: one position 0.177 -> 0.172 ms with 3 or 4 groups in flight
+    // (6 spills: 0.259); the same loads with the non-temporal hint: 0.258 ms (they lose their L2 hits)
+#ifndef OTH_WRING1
+#define OTH_WRING1 4
+#endif
+    constexpr int RING = TP == 1 ? OTH_WRING1 : 2;
+    static_assert(12 % RING == 0, "the ring index must be a compile-time function of the group");
+    uint4 wq[RING][8];
 #ifdef OTH_STAMPS
     unsigned long long ph_[4] = {0, 0, 0, 0}, t0_ = w_clk(), tstart_ = t0_;
     const unsigned long long rstart_ = w_realclk();
@@ -419,7 +428,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         if (layer == 0 && !last) {   // the first weight group of the first convolution; the later ones load theirs in
                                      // the previous convolution's last group
 #pragma unroll
-            for (int f = 0; f < 8; ++f) wq[0][f] = wl[(size_t)f * 64];
+            for (int g = 0; g < RING - 1; ++g)
+#pragma unroll
+                for (int f = 0; f < 8; ++f) wq[g][f] = wl[(size_t)g * (8 * 8 * 64) + (size_t)f * 64];
         }
         OTH_WSTAMP(0)
         wbarrier();   // every wave has finished reading V (or the stem's im2col)
@@ -470,8 +481,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                 const int q = D * 4 * GS + ql;
                 const int xi = q & 3, nt = (q >> 2) % NT, grp = q / GS, sl = q % (PD + 1), psl = (q + PD) % (PD + 1);
                 const int step = q % GS;                       // within the group
-                const half8 wh = __builtin_bit_cast(half8, wq[grp & 1][2 * xi]);
-                const half8 wlo = __builtin_bit_cast(half8, wq[grp & 1][2 * xi + 1]);
+                const half8 wh = __builtin_bit_cast(half8, wq[grp % RING][2 * xi]);
+                const half8 wlo = __builtin_bit_cast(half8, wq[grp % RING][2 * xi + 1]);
                 OTH_WSB;
                 if (q < GS) acc[xi][nt] = wmfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = wmfma(wh, xl[sl], acc[xi][nt]);
@@ -500,8 +511,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                     invn = a.inv[layer + 1];
                 }
                 if (step >= OTH_WLD0 && step < OTH_WLD0 + 8)
-                    wq[(grp + 1) & 1][step - OTH_WLD0] =
-                        wl[(size_t)(grp + 1) * (8 * 8 * 64) + (size_t)(step - OTH_WLD0) * 64];
+                    wq[(grp + RING - 1) % RING][step - OTH_WLD0] =
+                        wl[(size_t)(grp + RING - 1) * (8 * 8 * 64) + (size_t)(step - OTH_WLD0) * 64];
                 OTH_WSB;
                 acc[xi][nt] = wmfma(wlo, xh[sl], acc[xi][nt]);
                 OTH_WSB;
@@ -592,7 +603,7 @@ int wino_pack_weights(oth_net* net) {
     net->wino = ww;
     const size_t frag = 64 * 8;                              // halfs per fragment
     const size_t layer_halfs = (size_t)12 * 8 * 8 * frag;    // 12 groups x 8 waves x (4 xi x hi/lo)
-    std::vector<uint16_t> w((size_t)L * layer_halfs + 8 * 8 * frag), stem((size_t)8 * 2 * frag);   // + one zero group: the last conv's look-ahead
+    std::vector<uint16_t> w((size_t)L * layer_halfs + 5 * 8 * 8 * frag), stem((size_t)8 * 2 * frag);   // + zero groups: the last conv's look-ahead (ring depth - 1, at most 5)
     std::vector<float> bias((size_t)(L + 1) * 128), inv(L + 1);
     {   // stem: direct, gemm k = tap*3 + plane (27 of 32), rows = 16 channels of a wave
         const FoldedConv& cv = hn.stem;
