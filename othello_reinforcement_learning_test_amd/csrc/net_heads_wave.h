@@ -111,7 +111,8 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
     // One output column per pass (j), batches of U2 rows -- the shape of the policy FC above.  (A batch of U3 rows x 4
     // columns, i.e. 32 loads in flight feeding v_pk_fma_f32 pairs, gave wrong value outputs at ~1 % of the positions in
     // ONE instantiation -- 32 filters on 8x8 -- and only with two workgroups resident per CU: bitwise-stable policy
-    // outputs, scratch verified intact, full vmcnt(0) waits no cure, the rolled loop correct.  Not understood; this form
+    // outputs, scratch verified intact, full vmcnt(0) waits no cure, the rolled loop correct; a probe rules out late reads of
+    // the loads' scalar base / address registers (tools/probes/probe_saddr_war.hip).  Not understood; this form
     // measures the same speed and is correct everywhere: tools/probes/diag_v2.py.)
     constexpr int U4 = CELLS % 16 == 0 ? 16 : 12;
     static_assert(CELLS % U4 == 0, "batch size must divide the trip count");

@@ -359,7 +359,9 @@ def test_wave_trunks_ragged_batches(pkg, nb, nf, bs, prec):
 
 
 @pytest.mark.parametrize("nb,nf,bs,prec", [(2, 32, 8, "f16x3"), (2, 32, 6, "f16x3"), (5, 64, 8, "f16x3"), (5, 64, 6, "f16x3"),
-                                           (2, 16, 8, "f32"), (2, 16, 6, "f32"), (2, 128, 6, "f16x3")])
+                                           (2, 16, 8, "f32"), (2, 16, 6, "f32"), (2, 128, 6, "f16x3"),
+                                           (2, 128, 8, "f16x3"), (2, 128, 8, "f16x3_direct"), (2, 128, 8, "f32"),
+                                           (2, 32, 8, "f32"), (2, 32, 6, "f32"), (5, 64, 8, "f32"), (5, 64, 6, "f32")])
 def test_wave_trunks_full_occupancy_reproducible(pkg, nb, nf, bs, prec):
     """4096 positions per launch -- several workgroups resident per CU -- five times over: every output bit-identical from
     launch to launch and within 1e-4 of torch fp32.  (Round 3: a batched form of the value head's first FC gave wrong
