@@ -321,7 +321,8 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         }
         OTH_HSTAMP(1)
         // ---- epilogue: undo the weight scale, bias, skip connection (net.py:58-59), ReLU, re-split, rewrite in place.
-        //      add_res / set_res are compile-time flags of three instantiations (no v_cndmask per value).
+        //      add_res / set_res are compile-time flags of two instantiations (no v_cndmask per value); the stem takes the
+        //      skip form on a zero residual.
         auto epilogue = [&](auto ADD, auto SET) {
             constexpr bool add_res = decltype(ADD)::value;   // second conv of a block
             constexpr bool set_res = decltype(SET)::value;
