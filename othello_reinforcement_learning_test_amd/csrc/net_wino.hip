@@ -510,7 +510,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
                     b4n = *(const float4*)(a.bias + (layer + 1) * 128 + ch0);
                     invn = a.inv[layer + 1];
                 }
+#ifdef OTH_ABL_HALFW   // timing ablation only (wrong results): every second weight fragment keeps its stale registers
+                if (step >= OTH_WLD0 && step < OTH_WLD0 + 8 && ((step - OTH_WLD0) & 1) == 0)
+#else
                 if (step >= OTH_WLD0 && step < OTH_WLD0 + 8)
+#endif
                     wq[(grp + RING - 1) % RING][step - OTH_WLD0] =
                         wl[(size_t)(grp + RING - 1) * (8 * 8 * 64) + (size_t)(step - OTH_WLD0) * 64];
                 OTH_WSB;
