@@ -46,6 +46,7 @@ struct MfmaWeights;  // net_mfma.hip
 struct F32Weights;   // net_f32.hip
 struct H3Weights;    // net_h3.hip
 struct WinoWeights;  // net_wino.hip
+struct Wino6Weights; // net_wino6.hip
 
 }  // namespace oth
 
@@ -65,6 +66,8 @@ struct oth_net {
     oth::H3Weights* h3 = nullptr;
     // 1-D Winograd F(2,3) build of the 128-filter 8x8 trunk (fp16-split arithmetic): net_wino.hip
     oth::WinoWeights* wino = nullptr;
+    // 1-D Winograd F(2,3) build of the 64-filter 6x6 trunk (BASELINE configs[4]): net_wino6.hip
+    oth::Wino6Weights* wino6 = nullptr;
 };
 
 // The in-place MFMAs of net_mfma.hip / net_h3.hip are inline asm: hipcc inserts no wait states between a VALU write of a
@@ -87,6 +90,10 @@ int h3_pack_weights(oth_net* net);  // net_h3.hip
 void h3_free_weights(oth_net* net);
 int h3_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
                const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
+int wino6_pack_weights(oth_net* net);  // net_wino6.hip
+void wino6_free_weights(oth_net* net);
+int wino6_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
+                  const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 int wino_pack_weights(oth_net* net);  // net_wino.hip
 void wino_free_weights(oth_net* net);
 int wino_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,

@@ -90,6 +90,7 @@ static void net_free_device(oth_net* net) {
     h3_free_weights(net);
     mfma_free_weights(net);
     wino_free_weights(net);
+    wino6_free_weights(net);
 }
 
 extern "C" {
@@ -191,6 +192,13 @@ int oth_net_load_state(oth_net* net, const float* blob, int64_t n_floats, int pr
         r = wino_pack_weights(net);
         if (r != OTH_OK) return r;
     }
+    // A 64-filter 6x6 network (BASELINE configs[4]) in f16x3 runs the 6x6 Winograd trunk (net_wino6.hip: eight positions per
+    // workgroup, 1.5x fewer MFMAs and no padded cells); OTH_WINO6=0 keeps k_trunk_h3 -- the A/B switch.
+    const char* wino6_env = getenv("OTH_WINO6");
+    if (precision == OTH_PREC_F16X3 && net->filters == 64 && net->board == 6 && !(wino6_env && atoi(wino6_env) == 0)) {
+        r = wino6_pack_weights(net);
+        if (r != OTH_OK) return r;
+    }
     net->precision = precision;
     return OTH_OK;
 }
@@ -203,6 +211,7 @@ int oth_net_forward_bits(oth_net* net, const uint64_t* sb, const uint64_t* ob, c
     if (n == 0) return OTH_OK;
     OTH_BIND(net->device);
     if (net->precision == OTH_PREC_F32) return f32_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
+    if (net->wino6) return wino6_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     if (net->h3) return h3_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     if (net->wino) return wino_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));
     return mfma_forward(net, sb, ob, lg, n, n_valid, logp, v, as_stream(stream));

@@ -202,7 +202,7 @@ def test_no_mfma_hazards_in_built_objects():
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f) for f in ("net_mfma.o", "net_h3.o", "net_wino.o")]
+    objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f) for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o")]
     if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("object files / llvm-objdump not present (the .o files do not travel to the GPU box)")
     spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))

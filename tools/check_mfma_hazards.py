@@ -106,5 +106,5 @@ def main(paths):
 
 if __name__ == "__main__":
     args = sys.argv[1:] or [os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "csrc", f)
-                            for f in ("net_mfma.o", "net_h3.o", "net_wino.o")]
+                            for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o")]
     sys.exit(main(args))
