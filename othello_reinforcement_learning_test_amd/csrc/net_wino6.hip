@@ -61,12 +61,39 @@ struct Wino6Args {
     const float* pfc_wt;
     const float* vfc1_wt;
     int* sat;
+    unsigned long long* dbg;   // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
+
+#ifdef OTH_STAMPS
+__device__ __forceinline__ unsigned long long w6_clk() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ unsigned long long w6_realclk() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define OTH_W6STAMP(i) { const unsigned long long t1_ = w6_clk(); ph_[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define OTH_W6STAMP(i)
+#endif
 
 // The builtin, not the in-place inline asm of net_wino.hip: 36 accumulators + 18 residual registers + the weight ring need
 // more than 256 architectural VGPRs, and with asm MFMAs hipcc parked WEIGHT fragments in AGPRs and copied them back right
 // in front of their MFMA (no wait states: tools/check_mfma_hazards.py flagged every one).  With the builtin the allocator
 // may keep the accumulators themselves in AGPRs (MFMA reads and writes them there) and knows the hazards.
+// In-kernel stamps (-DOTH_STAMPS) of this build, per wave and layer: convolution 18.8 k cycles for 648 MFMAs (29 cycles per
+// MFMA), epilogue 6.6 k.  Timing ablations with fewer N-tiles and VGPR accumulators: 21.6 cycles per MFMA -- with one wave
+// per SIMD the two ds_read_b128 of a step cost their ~8 issue cycles each on top of its three MFMAs (48 + 16), and AGPR
+// accumulators add ~7 cycles per MFMA.  Not cured by a longer LDS look-ahead (3 / 4 / 6 steps), by interleaving the MFMAs
+// of two steps, or by asm MFMAs with the residual pinned into AGPRs (the allocator then migrates accumulators right after
+// their MFMA: 64 hazards).  Eight waves (two per SIMD, each with two of the four transformed taps) are the next step.
 __device__ __forceinline__ f32x4 w6mfma(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -80,7 +107,14 @@ __device__ __forceinline__ void w6barrier() {   // LDS-only barrier: global weig
 }
 #define OTH_W6SB __builtin_amdgcn_sched_barrier(0)
 
-__global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* __restrict__ sb,
+// All 512 registers per lane: nothing else is resident on the CU beside this workgroup -- in the two-lane engine the other
+// lane's tree kernel (70 VGPRs) then runs after the trunk instead of beside it (trunk share of the step 0.98 -> 0.92).  Capped
+// at 440 / 400 registers (-DOTH_W6REGS=220 / 200) the tree kernel is back beside it, but the spills cost more: 17.6 k / 17.0 k
+// games/s on configs[4] against 23.1 k uncapped (k_trunk_h3: 21.9 k on the same box).
+#ifndef OTH_W6REGS
+#define OTH_W6REGS 256   // x 2 = total registers per lane (VGPR + AGPR)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) void k_trunk_w6(Wino6Args a, const uint64_t* __restrict__ sb,
                                                   const uint64_t* __restrict__ ob, const uint64_t* __restrict__ lgl,
                                                   int64_t n, const int32_t* __restrict__ n_valid, float* __restrict__ logp,
                                                   float* __restrict__ vout) {
@@ -92,6 +126,10 @@ __global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* _
     }
     const int64_t pos0 = (int64_t)blockIdx.x * k6TP;
     if (pos0 >= nv) return;
+#ifdef OTH_STAMPS
+    unsigned long long ph_[5] = {0, 0, 0, 0, 0}, t0_ = w6_clk();   // prologue + stem | barrier waits | epilogues | convolutions | heads
+    const unsigned long long tstart_ = t0_, rstart_ = w6_realclk();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c = lane & 15;
 
@@ -187,6 +225,7 @@ __global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* _
 
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
+    OTH_W6STAMP(0)
     uint4 wq[2][8];   // weight ring: [group parity][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments
     float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x 2^4) and 1 / weight scale of the layer in the epilogue
     float inv = a.inv[0], invn = inv;
@@ -262,7 +301,7 @@ __global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* _
                         }
                     }
                 }
-                OTH_W6SB;   // one lane group at a time
+                OTH_W6SB;   // one lane group at a time (without it: no change)
             }
         };
         using T_ = std::true_type;
@@ -272,11 +311,15 @@ __global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* _
 #pragma unroll
             for (int f = 0; f < 8; ++f) wq[0][f] = wl[(size_t)f * 64];
         }
+        OTH_W6STAMP(3)
         w6barrier();   // every wave has finished reading V (or the stem's im2col)
+        OTH_W6STAMP(1)
         if (layer & 1) epilogue(F_{});
         else epilogue(T_{});
+        OTH_W6STAMP(2)
         if (last) break;
         w6barrier();
+        OTH_W6STAMP(1)
 
         // ---------------- conv `layer+1` in the Winograd domain: 6 groups (row tap d, k-step kk) x 36 steps (N-tile, xi) x
         // 3 split products.  One straight-line software pipeline per row tap: the two LDS reads of step q+2 and, spread
@@ -369,6 +412,15 @@ __global__ __launch_bounds__(256) void k_trunk_w6(Wino6Args a, const uint64_t* _
         }
         heads_wave_n<k6F, k6BS, 2>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
     }
+#ifdef OTH_STAMPS
+    OTH_W6STAMP(4)
+    if (a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ph_[i];
+        o[5] = w6_clk() - tstart_;
+        o[6] = w6_realclk() - rstart_;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,6 +552,27 @@ int wino6_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const ui
         attr_set = true;
     }
     const unsigned grid = (unsigned)((n + k6TP - 1) / k6TP);
+#ifdef OTH_STAMPS
+    OTH_HIP(hipMalloc(&a.dbg, (size_t)grid * 4 * 8 * sizeof(unsigned long long)));
+    OTH_HIP(hipMemset(a.dbg, 0, (size_t)grid * 4 * 8 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_trunk_w6, dim3(grid), dim3(256), k6Lds, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    OTH_HIP(hipStreamSynchronize(stream));
+    {
+        std::vector<unsigned long long> h((size_t)grid * 4 * 8);
+        OTH_HIP(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double sm[7] = {0, 0, 0, 0, 0, 0, 0};
+        size_t nw = 0;
+        for (size_t w = 0; w < (size_t)grid * 4; ++w) {
+            if (!h[w * 8 + 5]) continue;
+            ++nw;
+            for (int i = 0; i < 7; ++i) sm[i] += (double)h[w * 8 + i];
+        }
+        fprintf(stderr, "[w6 stamps] per-wave cycles: prologue+stem %.0f | barrier waits %.0f | epilogues %.0f | convolutions %.0f | heads %.0f | total %.0f | clock %.3f GHz\n",
+                sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, sm[5] / nw, sm[5] / sm[6] * 0.1);
+        (void)hipFree(a.dbg);
+    }
+    return OTH_OK;
+#endif
     hipLaunchKernelGGL(k_trunk_w6, dim3(grid), dim3(256), k6Lds, stream, a, sb, ob, lg, n, n_valid, logp, v);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
