@@ -676,6 +676,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w6b(Wino6Args a, const uint64_
                 const int q = D * 2 * GS + ql;
                 const int xl = q & 1, nt = (q >> 1) % k6NT, grp = q / GS, sl = q % (PD + 1), psl = (q + PD) % (PD + 1);
                 const int step = q % GS;
+#ifdef OTH_W6B_NTLO   // timing ablation only (wrong results): N-tiles [OTH_W6B_NTLO, OTH_W6B_NTHI) only
+                if (nt < OTH_W6B_NTLO || nt >= OTH_W6B_NTHI) continue;
+#endif
                 const half8 wh = __builtin_bit_cast(half8, wq[grp & 1][2 * xl]);
                 const half8 wlo = __builtin_bit_cast(half8, wq[grp & 1][2 * xl + 1]);
                 OTH_W6SB;
