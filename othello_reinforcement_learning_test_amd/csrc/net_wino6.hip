@@ -872,7 +872,7 @@ int wino6_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const ui
     }
     const unsigned grid = (unsigned)((n + k6TP - 1) / k6TP);
     {
-        static const char* e = getenv("OTH_WINO6");
+        const char* e = getenv("OTH_WINO6");   // read per call: the variants test toggles it
         if (e && atoi(e) == 2) {   // the eight-wave build (experiment switch)
             static bool attr_b[64] = {};
             if (!attr_b[net->device & 63]) {

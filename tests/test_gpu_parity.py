@@ -459,6 +459,40 @@ def test_trunk_kernel_variants_agree(pkg):
         assert (x - outs[0]).abs().max().item() < 5e-6
 
 
+def test_wino6_variants_agree(pkg):
+    """BASELINE configs[4]'s network (5 x 64 on 6x6) through its three trunk builds -- k_trunk_h3 (OTH_WINO6=0), the Winograd
+    trunk k_trunk_w6 (default) and its eight-wave form (OTH_WINO6=2): each within 1e-4 of torch fp32, the two Winograd builds
+    bit-identical to each other (same arithmetic, same order), k_trunk_h3 within 1e-5 of them; ragged batch sizes included."""
+    import os
+    torch.manual_seed(3)
+    net = pkg.OthelloResNet(5, 64, board_size=6).eval()
+    rng = np.random.Generator(np.random.PCG64(17))
+    old = os.environ.get("OTH_WINO6")
+    try:
+        for n in (1, 7, 8, 9, 1000):
+            occ = rng.random((n, 6, 6)) < 0.5
+            own = occ & (rng.random((n, 6, 6)) < 0.5)
+            x = torch.from_numpy(np.stack([own, occ & ~own, (~occ) & (rng.random((n, 6, 6)) < 0.4)], 1).astype(np.float32)).cuda()
+            with torch.no_grad():
+                rl, rv = net.cuda()(x)
+            net.cpu()
+            outs = {}
+            for mode in ("0", "1", "2"):
+                os.environ["OTH_WINO6"] = mode
+                ev = pkg.HipResNetEvaluator(net, precision="f16x3")
+                logp, v = ev.forward_planes(x)
+                torch.cuda.synchronize()
+                assert (logp - rl).abs().max().item() < 1e-4 and (v - rv).abs().max().item() < 1e-4, (n, mode)
+                outs[mode] = (logp.clone(), v.clone())
+            assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1]), n
+            assert (outs["0"][0] - outs["1"][0]).abs().max().item() < 1e-5, n
+    finally:
+        if old is None:
+            os.environ.pop("OTH_WINO6", None)
+        else:
+            os.environ["OTH_WINO6"] = old
+
+
 @pytest.mark.parametrize("blocks,filters,board", [(2, 128, 8), (2, 64, 8), (2, 32, 6)])
 def test_trunk_saturation_is_surfaced(pkg, blocks, filters, board):
     """The fp16-split trunk kernels clamp activations at 3750; the reference's fp32 forward does not.  A network whose
