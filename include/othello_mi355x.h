@@ -129,11 +129,21 @@ int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *o
                          int64_t n, const int32_t *n_valid, float *logp, float *v, void *stream);
 /* forward(x) for x float32 [n,3,S,S] holding 0/1 planes (the reference's input format) DEVICE */
 int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
-/* The fp16-split trunk kernels (OTH_PREC_F16X3 / OTH_PREC_F16) clamp activations to 3750 (the f16 range of the hi
- * parts after the 2^4 pre-scale); the reference's fp32 forward (net.py:182-205) does not.  *flag = 1 when any launch
+/* The fp16-split trunk kernels (OTH_PREC_F16X3 / OTH_PREC_F16) clamp activations: the direct kernels (k_trunk16,
+ * k_trunk_h3) at 3750 (the f16 range of the hi parts after the 2^4 pre-scale), the Winograd trunks (k_trunk_w, k_trunk_w6:
+ * the DEFAULT for 128 filters on 8x8 and 64 filters on 6x6) at 1875 (their transformed operand is up to twice an
+ * activation); the reference's fp32 forward (net.py:182-205) does not.  *flag = 1 when any launch
  * since the last call clamped a value -- the results then differ from the reference: reload the weights with
  * OTH_PREC_F32.  Reads and clears a device flag; synchronises `stream`.  HOST flag. */
 int oth_net_saturated(oth_net *net, int32_t *flag, void *stream);
+/* Which trunk kernel a launch of n positions of this network runs (no reference counterpart: the reference's forward,
+ * net.py:182-205, is torch ops; measurement needs the kernel's name and its arithmetic factor from the library, not
+ * re-derived by the caller): `name` (HOST, name_cap bytes, NUL-terminated), *issued_per_flop = MFMA FLOPs the kernel
+ * issues per algorithmic FLOP of the direct 3x3 convolutions (1.0 exact fp32; 2.75 k_trunk16; 2.0 the Winograd trunks;
+ * 3.0 x tile padding k_trunk_h3), *clamp = the activation clamp reported by oth_net_saturated (0 = none).  Any output
+ * pointer may be NULL.  Needs loaded weights; no device work. */
+int oth_net_kernel_info(const oth_net *net, int64_t n, char *name, int32_t name_cap, double *issued_per_flop,
+                        double *clamp);
 
 /* probs[i] = exp(logp[i]) exactly as the engine's expansion computes it from the network's log-probabilities
  * (mcts.py:189 / parallel_self_play.py:72-76 `policy_probs = torch.exp(policy_logits)`): lets an external

@@ -76,6 +76,7 @@ _SIGS = {
     "oth_net_forward_bits": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
     "oth_net_forward_planes": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
     "oth_net_saturated": (C.c_int, [vp, i32p, vp]),
+    "oth_net_kernel_info": (C.c_int, [vp, C.c_int64, C.c_char_p, C.c_int32, f64p, f64p]),
     "oth_policy_exp": (C.c_int, [vp, vp, C.c_int64, vp]),
     "oth_engine_create": (vp, [C.POINTER(EngineCfg)]),
     "oth_engine_destroy": (None, [vp]),

@@ -138,6 +138,46 @@ int oth_net_saturated(oth_net* net, int32_t* flag, void* stream) {
     return OTH_OK;
 }
 
+int oth_net_kernel_info(const oth_net* net, int64_t n, char* name, int32_t name_cap, double* issued_per_flop,
+                        double* clamp) {
+    OTH_CHECK(net && net->precision >= 0, "oth_net_kernel_info: no weights loaded (call oth_net_load_state)");
+    // the same order of tests as oth_net_forward_bits below
+    const char* k;
+    double issued, cl = 0.0;
+    if (net->precision == OTH_PREC_F32) {
+        k = "k_trunk_f32 (fused ResNet forward, exact fp32 on v_mfma_f32_16x16x4_f32, one wave per position group)";
+        issued = 1.0;
+    } else if (net->wino6) {
+        k = "k_trunk_w6 (fused ResNet forward, 6x6, 1-D Winograd F(2,3) residual convolutions, eight positions per workgroup)";
+        issued = 3.0 * 2.0 / 3.0;   // three split products, 4 multiplies per 2 outputs instead of 6, every N-tile full
+        cl = 1875.0;
+    } else if (net->h3) {
+        k = "k_trunk_h3 (fused ResNet forward, direct 3x3, one wave per position group)";
+        // three split products; N-tiles of 16 cells over the wave's positions (P = 2 on 6x6 with 64 filters, 4 with 32, else 1)
+        const int cells = net->board * net->board;
+        const int P = net->board == 6 ? (net->filters == 64 ? 2 : net->filters == 32 ? 4 : 1) : 1;
+        issued = 3.0 * (double)((P * cells + 15) / 16 * 16) / (double)(P * cells);
+        cl = 3750.0;
+    } else if (net->wino) {
+        k = n > 256 ? "k_trunk_w<2> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, two positions per workgroup)"
+                    : "k_trunk_w<1> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, one position per workgroup)";
+        issued = 3.0 * 2.0 / 3.0;
+        cl = 1875.0;
+    } else {
+        const bool x3 = net->precision != OTH_PREC_F16;
+        k = x3 ? "k_trunk16 (fused ResNet forward, direct 3x3, fp16 hi/lo split)" : "k_trunk16 (fused ResNet forward, direct 3x3, single fp16 pass)";
+        issued = (x3 ? 3.0 : 1.0) * 11.0 / 12.0;   // the all-padding row tiles of the dy = -1 / +1 taps are skipped
+        cl = 3750.0;
+    }
+    if (name && name_cap > 0) {
+        strncpy(name, k, (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (issued_per_flop) *issued_per_flop = issued;
+    if (clamp) *clamp = cl;
+    return OTH_OK;
+}
+
 int64_t oth_net_state_floats(const oth_net* net) { return net ? state_floats(net->blocks, net->filters, net->board) : 0; }
 int oth_net_policy_size(const oth_net* net) { return net ? net->board * net->board + 1 : 0; }
 

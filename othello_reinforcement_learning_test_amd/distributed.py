@@ -43,6 +43,13 @@ def _gather_buffers(dev, dtype, row, world, nmax, total):
     return buf
 
 
+def release_gather_buffers():
+    """Drop the persistent exchange buffers (up to ~1.8 GB at 8 ranks x 100 k tuples): call when self-play is over and
+    the memory is wanted for something else; the next exchange allocates them again.  Views returned by earlier
+    ``all_gather_replay`` calls keep their storage alive until they are dropped too."""
+    _GATHER_BUFFERS.clear()
+
+
 def all_gather_replay(states, pis, zs, group=None, force=False):
     """All-gather variable-length replay tuples.  Inputs are torch tensors (or lists of tensors, concatenated in
     order) on one device (CUDA for RCCL, CPU for gloo) with a common leading length n_r.  Returns (states, pis, zs, counts) where the
@@ -98,17 +105,27 @@ class DistributedSelfPlayWorker:
     """``execute_episodes`` with the reference's signature for a job of WORLD_SIZE processes: each rank
     plays ``shard_episodes`` games on its own GPU, then all ranks receive all tuples."""
 
-    def __init__(self, worker, rank=None, world_size=None, base_seed=0, group=None):
+    def __init__(self, worker, rank=None, world_size=None, base_seed=0, group=None, force_collectives=None):
+        import os
+
         import torch.distributed as dist
         self.worker = worker  # a ParallelSelfPlayWorker bound to this rank's GPU
         self.group = group
+        # run the collectives even on a one-rank group (the RCCL smoke test of the GPU suite: OTHELLO_FORCE_DIST=1)
+        self.force_collectives = bool(os.environ.get("OTHELLO_FORCE_DIST")) if force_collectives is None \
+            else bool(force_collectives)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self.base_seed = int(base_seed)
         self._calls = 0
 
-    def execute_episodes_tensors(self, num_episodes, add_dirichlet_noise=True):
-        """-> CUDA tensors (states, pis, zs) of the WHOLE job, plus per-rank tuple counts."""
+    def execute_episodes_tensors(self, num_episodes, add_dirichlet_noise=True, copy=True):
+        """-> CUDA tensors (states, pis, zs) of the WHOLE job, plus per-rank tuple counts.
+
+        ``copy=True`` (default): fresh tensors the caller owns -- a trainer may keep the result of call k alive while it
+        makes call k+1 (the reference's replay_buffer.add keeps references, trainer.py:185).  ``copy=False``: zero-copy
+        VIEWS of the persistent exchange buffers (``all_gather_replay``) or of the engine's compacted tuples, valid only
+        until the next call on this device -- for consumers that copy at once (bench.py, DeviceReplayBuffer.add)."""
         mine = shard_episodes(num_episodes, self.rank, self.world_size)
         if getattr(self.worker, "_streaming", False):
             raise RuntimeError("DistributedSelfPlayWorker needs a batch-mode worker (continuous=False): a batch run "
@@ -127,10 +144,13 @@ class DistributedSelfPlayWorker:
             st = torch.empty((0, 3, eng.board_size, eng.board_size), dtype=torch.float32, device="cuda")   # 6x6: (0,3,6,6)
             pi = torch.empty((0, eng.npol), dtype=torch.float32, device="cuda")
             z = torch.empty((0,), dtype=torch.float32, device="cuda")
-        return all_gather_replay(st, pi, z, self.group)
+        st, pi, z, counts = all_gather_replay(st, pi, z, self.group, force=self.force_collectives)
+        if copy:
+            st, pi, z = st.clone(), pi.clone(), z.clone()
+        return st, pi, z, counts
 
     def execute_episodes(self, num_episodes, add_dirichlet_noise=True):
-        st, pi, z, _ = self.execute_episodes_tensors(num_episodes, add_dirichlet_noise)
+        st, pi, z, _ = self.execute_episodes_tensors(num_episodes, add_dirichlet_noise, copy=False)
         st, pi, z = st.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
         return [(st[i].copy(), pi[i].copy(), float(z[i])) for i in range(len(z))]
 

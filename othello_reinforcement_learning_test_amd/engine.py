@@ -86,8 +86,17 @@ class HipResNetEvaluator:
                   n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
         return logp, v.view(n, 1)
 
+    def kernel_info(self, n_positions=4096):
+        """Which trunk kernel a launch of ``n_positions`` runs, as the library itself dispatches it:
+        {"kernel": name, "issued_per_flop": MFMA FLOPs issued per algorithmic FLOP, "clamp": activation clamp or 0}."""
+        name = C.create_string_buffer(256)
+        issued, clamp = C.c_double(0), C.c_double(0)
+        _lib.call("oth_net_kernel_info", self._h, int(n_positions), name, 256, C.byref(issued), C.byref(clamp))
+        return {"kernel": name.value.decode(), "issued_per_flop": issued.value, "clamp": clamp.value}
+
     def saturated(self):
-        """True when an fp16-split trunk launch since the last call clamped an activation at 3750 (the reference's
+        """True when an fp16-split trunk launch since the last call clamped an activation (at 3750 in the direct
+        kernels, 1875 in the Winograd trunks that are the default for 10x128 on 8x8 and 5x64 on 6x6; the reference's
         fp32 forward has no clamp): reads and clears the device flag (one 4-byte copy, synchronises the stream)."""
         flag = C.c_int32(0)
         _lib.call("oth_net_saturated", self._h, C.byref(flag), _lib.current_stream())
@@ -97,10 +106,11 @@ class HipResNetEvaluator:
         """Loud failure instead of a silent deviation from the reference: called by the workers and the search mirrors
         at the end of every call (they synchronise there anyway)."""
         if self.precision != "f32" and self.saturated():
+            info = self.kernel_info()
             raise _lib.OthelloHipError(
-                "an activation of the %dx%d network exceeded 3750, the range of the fp16-split trunk kernel: results "
+                "an activation of the %dx%d network exceeded %g, the range of the fp16-split trunk kernel %s: results "
                 "would differ from the reference's fp32 forward -- build the evaluator with precision='f32'"
-                % (self.num_blocks, self.num_filters))
+                % (self.num_blocks, self.num_filters, info["clamp"], info["kernel"].split(" ")[0]))
 
     def policy_probs(self, logp):
         """exp(log-probs) with the engine's own expf (what the expansion feeds node.py:71-80): CUDA tensor in/out."""
@@ -122,12 +132,19 @@ class HipResNetEvaluator:
 def policy_from_visits(visits, self_b, opp_b, temperature, board_size=8):
     """MCTSNode.get_policy_distribution for a general temperature (/root/reference/src/mcts/node.py:162-182), the same
     numpy expressions in the same order on the root's children (= the legal moves in ascending order, or the pass):
-    float32 counts ** (1.0 / T), /= counts.sum(), scatter.  Bit-identical to the reference by construction."""
+    float32 counts ** (1.0 / T), /= counts.sum(), scatter.  Bit-identical to the reference by construction.
+
+    A TERMINAL root is not node.py:164's childless case: get_legal_moves() returns [64] there (bitboard.pyx:177-185), the
+    root is expanded with the pass child and every simulation is backed up through it, so the policy is one-hot on the
+    pass at every temperature (fixture g9, generated by the reference).  Only a search of zero simulations has all-zero
+    counts, and there the reference itself evaluates 0/0; this mirror then returns the zero vector instead of NaN."""
     npol = board_size * board_size + 1
     policy = np.zeros(npol, dtype=np.float32)
     legal = int(_lib.load().oth_legal_moves_n(board_size, self_b, opp_b))
     actions = [a for a in range(npol - 1) if (legal >> a) & 1] or [npol - 1]
     counts = np.array([visits[a] for a in actions], dtype=np.float32)
+    if not counts.any():
+        return policy
     if temperature == 0:
         policy[actions[int(np.argmax(counts))]] = 1.0
     else:

@@ -212,13 +212,21 @@ def train_epochs(model, optimizer, buffer, num_epochs, batch_size, scaler=None):
 
 
 def infer_architecture(state_dict):
-    """(num_blocks, num_filters) from parameter names, as players.py:186-202 does."""
+    """(num_blocks, num_filters, board_size) from a state_dict.  Blocks and filters from the parameter names and the
+    stem's shape as players.py:186-202 does; the board size from the policy head's FC (net.py:81: S*S+1 rows, so
+    65 -> 8 and 37 -> 6), which the reference ignores -- its from_checkpoint always builds an 8x8 net and a 6x6
+    checkpoint (configs/debug_6x6.yaml) fails in load_state_dict there."""
     blocks = 0
     for k in state_dict:
         if k.startswith("res_blocks."):
             blocks = max(blocks, int(k.split(".")[1]) + 1)
     filters = int(state_dict["conv_block.conv.weight"].shape[0])
-    return blocks, filters
+    rows = int(state_dict["policy_head.fc.weight"].shape[0])
+    board = int(round((rows - 1) ** 0.5))
+    if board * board + 1 != rows or int(state_dict["policy_head.fc.weight"].shape[1]) != 2 * board * board:
+        raise ValueError("policy_head.fc.weight %s is not (S*S+1, 2*S*S) for any board size S"
+                         % (tuple(state_dict["policy_head.fc.weight"].shape),))
+    return blocks, filters, board
 
 
 def load_checkpoint_model(path, map_location="cpu"):
@@ -229,7 +237,7 @@ def load_checkpoint_model(path, map_location="cpu"):
     from .net import OthelloResNet
     obj = torch.load(path, map_location=map_location, weights_only=True)
     sd = obj["model_state_dict"] if isinstance(obj, dict) and "model_state_dict" in obj else obj
-    blocks, filters = infer_architecture(sd)
-    model = OthelloResNet(blocks, filters).eval()
+    blocks, filters, board = infer_architecture(sd)
+    model = OthelloResNet(blocks, filters, board_size=board).eval()
     model.load_state_dict(sd)
     return model

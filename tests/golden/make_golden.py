@@ -20,6 +20,9 @@ are stored (fixtures G1..G5).  Files are small (each wel
   g8_extra.npz     OthelloBitboard.get_symmetries of 120 positions with random pi (8 boards + 8 policies each), and
                    MCTS.search at temperatures 0.5 and 2.0 (node.py:175-177's counts ** (1/T)) under the stub evaluator
                    (--only-g8 writes just this file; g7 is tests/golden/make_golden_net6.py)
+  g9_terminal.npz  MCTS.search / BatchMCTS.search_batch / get_best_action started AT a terminal position (the root gets
+                   the single pass child, mcts.py:76-82 with bitboard.pyx:177-185; every simulation backs the winner up
+                   through it): policies at T = 0 / 0.5 / 1 / 2  (--only-g9)
 """
 import hashlib
 import os
@@ -509,8 +512,51 @@ def gen_extra():
     print("g8: %d symmetry cases, %d temperature cases" % (len(sym_pos), len(cases)))
 
 
+def gen_terminal():
+    """g9: searches whose ROOT is terminal (round-3 advisor finding: no fixture covered it)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    stub = StubModel()
+    dev = torch.device("cpu")
+    finals = []
+    while len(finals) < 24:
+        b = bb.OthelloBitboard()
+        b.reset()
+        while not b.is_terminal():
+            mv = b.get_legal_moves()
+            assert b.make_move(int(mv[rng.integers(len(mv))]))
+        if (int(b.self_board), int(b.opp_board)) not in finals:
+            finals.append((int(b.self_board), int(b.opp_board)))
+    cases, pol = [], []
+    for s, o in finals:
+        for temp in (0.0, 0.5, 1.0, 2.0):
+            for sims in (1, 10):
+                m = MCTS(stub, dev, c_puct=1.0)
+                pi, rv = m.search(board_from(s, o), sims, temperature=temp, add_dirichlet_noise=False)
+                assert rv == 0.0 and pi.dtype == np.float32
+                cases.append((s, o, sims, int(temp * 1000)))
+                pol.append(pi)
+    bm = BatchMCTS(stub, dev, c_puct=1.0)
+    res = bm.search_batch([board_from(s, o) for s, o in finals], 8, temperature=1.0, add_dirichlet_noise=False)
+    batch_pi = np.stack([p for p, _ in res])
+    m = MCTS(stub, dev, c_puct=1.0)
+    best = [m.get_best_action(board_from(s, o), 5) for s, o in finals]
+    np.savez_compressed(
+        os.path.join(HERE, "g9_terminal.npz"),
+        pos=np.array(finals, dtype=U64),
+        case_pos=np.array([[c[0], c[1]] for c in cases], dtype=U64),
+        case_cfg=np.array([[c[2], c[3]] for c in cases], dtype=np.int32),
+        policy=np.array(pol, dtype=np.float32), batch_pi=batch_pi.astype(np.float32),
+        best_action=np.array(best, dtype=np.int32), stub_logits=STUB_LOGITS,
+    )
+    print("g9: %d terminal roots, %d cases; pi[64] values %s; best %s"
+          % (len(finals), len(cases), np.unique(np.array(pol)[:, 64]), np.unique(best)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if "--only-g9" in sys.argv:
+        gen_terminal()
+        sys.exit(0)
     if "--only-arena" in sys.argv:
         gen_arena()
         sys.exit(0)

@@ -156,3 +156,69 @@ def test_exchange_step_world8_gloo():
     assert all(ok for _, ok, _ in res)
     shares = [s for _, _, s in res]
     assert all(s == shares[0] for s in shares) and sum(shares[0]) == 8 * 1536   # identical on every rank, total fixed
+
+
+class _FakeEngine:
+    """Stands in for SearchEngine in the CPU test below: seeded CPU tuples instead of a device run."""
+    board_size, npol = 8, 65
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, 0
+
+    def selfplay_run(self, n, seed, noise):
+        self.calls += 1
+        self._t = _make(1000 * self.calls + self.rank, 50 * n + self.rank)
+
+    def selfplay_device_tensors(self):
+        return self._t
+
+
+class _FakeWorker:
+    def __init__(self, rank):
+        self.engine = _FakeEngine(rank)
+        self.batch_mcts = type("B", (), {"evaluator": type("E", (), {"refresh": staticmethod(lambda: None)})()})()
+
+
+def _worker_hold(rank, world, port, q):
+    """A trainer holding the result of call k across call k+1 (round-3 advisor finding): execute_episodes_tensors
+    returns tensors the caller owns by default; copy=False returns views of the persistent exchange buffers, which the
+    next call overwrites; release_gather_buffers drops them."""
+    from othello_reinforcement_learning_test_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = D.DistributedSelfPlayWorker(_FakeWorker(rank), base_seed=3)
+        a = w.execute_episodes_tensors(4)                       # 2 games per rank -> 100 + rank tuples each
+        keep = [t.clone() for t in a[:3]]
+        b = w.execute_episodes_tensors(4)
+        ok = a[3] == [100, 101] and all(torch.equal(x, y) for x, y in zip(a[:3], keep))      # call 1 survived call 2
+        ok &= not torch.equal(a[0], b[0])
+        c = w.execute_episodes_tensors(4, copy=False)
+        cv = [t.clone() for t in c[:3]]
+        d = w.execute_episodes_tensors(4, copy=False)
+        ok &= c[0].data_ptr() == d[0].data_ptr() and not torch.equal(c[0], cv[0])           # views: overwritten
+        exp = [_make(1000 * 4 + r, 100 + r) for r in range(world)]
+        ok &= torch.equal(d[0], torch.cat([e[0] for e in exp])) and torch.equal(d[2], torch.cat([e[2] for e in exp]))
+        ok &= len(D._GATHER_BUFFERS) == 3
+        D.release_gather_buffers()
+        ok &= len(D._GATHER_BUFFERS) == 0
+        e = w.execute_episodes_tensors(4)                      # allocates again
+        ok &= e[3] == [100, 101] and len(D._GATHER_BUFFERS) == 3
+        q.put((rank, bool(ok), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_worker_results_survive_the_next_call():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hold, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)

@@ -211,3 +211,55 @@ def test_no_mfma_hazards_in_built_objects():
     for o in objs:
         n, bad = mod.check_object(o)
         assert n > 500 and not bad, bad[:3]
+
+
+def test_hazard_checker_sees_across_branch_edges():
+    """The checker on synthetic disassembly (round-3 advisor finding: it only modelled straight-line code): a VALU write
+    at the END of a loop body followed by the back-edge to an asm MFMA at the loop top, an MFMA result consumed right
+    after a forward branch, the same two patterns made safe by wait states, and intervening MFMAs counted as 4 states."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def asm(lines):
+        """[(mnemonic, operands)] -> objdump-style text with addresses; ('L', name) places a label, branches name one."""
+        addr, labels, rows = 0x1000, {}, []
+        for mn, ops in lines:
+            if mn == "L":
+                labels[ops] = addr
+                continue
+            rows.append((addr, mn, ops))
+            addr += 8 if mn.startswith("v_mfma") else 4
+        out = ["0000000000001000 <k>:"]
+        for a, mn, ops in rows:
+            enc = 0xBF800000
+            if mn.startswith("s_cbranch") or mn == "s_branch":
+                enc = 0xBF850000 | (((labels[ops] - a - 4) // 4) & 0xFFFF)
+                ops = str((labels[ops] - a - 4) // 4)
+            out.append("\t%s %s // %012X: %08X" % (mn, ops, a, enc))
+        return "\n".join(out)
+    mfma = ("v_mfma_f32_16x16x32_f16", "v[0:3], v[8:11], v[12:15], v[0:3]")
+    # (1) loop: top = asm MFMA reading v8; bottom = VALU write of v8, then the back-edge
+    loop_bad = asm([("L", "top"), mfma, ("s_nop", "7"), ("s_nop", "7"), ("v_add_f32_e32", "v8, v20, v21"),
+                    ("s_cbranch_scc1", "top"), ("s_endpgm", "")])
+    n, bad, edges, _ = mod.check_text(loop_bad)
+    assert n == 1 and edges == 1 and len(bad) == 1 and "writes a source" in bad[0]
+    loop_ok = asm([("L", "top"), mfma, ("s_nop", "7"), ("s_nop", "7"), ("v_add_f32_e32", "v8, v20, v21"), ("s_nop", "0"),
+                   ("s_cbranch_scc1", "top"), ("s_endpgm", "")])
+    assert mod.check_text(loop_ok)[1] == []
+    # (2) forward branch: the MFMA's result read 2 states later at the target; linear scan alone would not see it
+    fwd_bad = asm([mfma, ("s_branch", "out"), ("s_nop", "7"), ("s_nop", "7"), ("L", "out"), ("v_mov_b32_e32", "v30, v1"),
+                   ("s_endpgm", "")])
+    n, bad, edges, _ = mod.check_text(fwd_bad)
+    assert edges == 1 and len(bad) == 1 and "touches the result" in bad[0]
+    fwd_ok = asm([mfma, ("s_nop", "7"), ("s_nop", "2"), ("s_branch", "out"), ("s_nop", "0"), ("L", "out"),
+                  ("v_mov_b32_e32", "v30, v1"), ("s_endpgm", "")])
+    assert mod.check_text(fwd_ok)[1] == []
+    # (3) three other MFMAs in between = 12 states: the pipe takes one MFMA per 4 passes
+    other = ("v_mfma_f32_16x16x32_f16", "v[4:7], v[8:11], v[12:15], v[4:7]")
+    assert mod.check_text(asm([mfma, other, other, other, ("v_mov_b32_e32", "v30, v1")]))[1] == []
+    assert len(mod.check_text(asm([mfma, other, other, ("v_mov_b32_e32", "v30, v1")]))[1]) == 1
+    assert mod.find_objdump()

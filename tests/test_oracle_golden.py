@@ -116,6 +116,25 @@ def test_search_general_temperature(stub, golden):
         assert np.array_equal(policy_from_visits(gn, int(s), int(o), t1000 / 1000.0), pi)
 
 
+def test_search_at_terminal_root(stub, golden):
+    """A search STARTED at a terminal position (g9, generated by the reference): get_legal_moves() is [64] there
+    (bitboard.pyx:177-185), so the root gets the pass child, every simulation backs the winner up through it and pi is
+    one-hot on 64 at every temperature -- never node.py:164's all-zero vector and never 0/0.  Oracle and the package's
+    host mirror of node.py:162-182."""
+    from othello_reinforcement_learning_test_amd.engine import policy_from_visits
+    _, ev = stub
+    g = golden("g9_terminal.npz")
+    for (s, o), (sims, t1000), pi in zip(g["case_pos"], g["case_cfg"], g["policy"]):
+        b = ol.board(s, o)
+        assert ol.lib().orc_is_terminal(b)
+        gpi, gn, _, _ = ol.search(b, int(sims), 1.0, t1000 / 1000.0, ev)
+        assert np.array_equal(gpi, pi) and gn[64] == sims and gn[:64].sum() == 0
+        assert np.array_equal(policy_from_visits(gn, int(s), int(o), t1000 / 1000.0), pi)
+    boards = [ol.board(s, o) for s, o in g["pos"]]
+    pi, _ = ol.search_batch(boards, 8, 1.0, 1.0, ev)
+    assert np.array_equal(pi, g["batch_pi"])
+
+
 def test_symmetries_vs_reference(golden):
     """orc_symmetries == OthelloBitboard.get_symmetries (bitboard.pyx:338-370) on 120 positions with random pi:
     8 boards (literal rot90 / flip of all three planes) and 8 policies each, bit for bit (fixture g8)."""

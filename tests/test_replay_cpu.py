@@ -114,7 +114,7 @@ def test_train_step_is_the_trainers_formula():
 def test_checkpoint_loader_roundtrip(tmp_path):
     torch.manual_seed(3)
     net = OthelloResNet(3, 32)
-    assert infer_architecture(net.state_dict()) == (3, 32)
+    assert infer_architecture(net.state_dict()) == (3, 32, 8)
     # the trainer's format (reference trainer.py:375-384) and a bare state_dict
     p1, p2 = tmp_path / "ckpt.pt", tmp_path / "sd.pt"
     torch.save({"model_state_dict": net.state_dict(), "global_step": 5, "epoch": 1,
@@ -129,6 +129,23 @@ def test_checkpoint_loader_roundtrip(tmp_path):
         with torch.no_grad():
             out = m(x)
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    # a BASELINE configs[4] checkpoint (6x6: policy FC 37 x 72, value FC1 256 x 36) -- the reference's
+    # players.py:186-211 builds an 8x8 net for it and fails in load_state_dict
+    torch.manual_seed(4)
+    net6 = OthelloResNet(5, 64, board_size=6)
+    assert infer_architecture(net6.state_dict()) == (5, 64, 6)
+    p3 = tmp_path / "ckpt6.pt"
+    torch.save({"model_state_dict": net6.state_dict(), "global_step": 1}, p3)
+    m6 = load_checkpoint_model(str(p3))
+    assert (m6.num_blocks, m6.num_filters, m6.board_size) == (5, 64, 6) and not m6.training
+    x6 = torch.rand(3, 3, 6, 6)
+    with torch.no_grad():
+        r6, o6 = net6.eval()(x6), m6(x6)
+    assert tuple(o6[0].shape) == (3, 37) and torch.equal(o6[0], r6[0]) and torch.equal(o6[1], r6[1])
+    bad = dict(net6.state_dict())
+    bad["policy_head.fc.weight"] = torch.zeros(51, 98)
+    with pytest.raises(ValueError):
+        infer_architecture(bad)
 
 
 def test_buffer_carries_6x6_tuples():

@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""Static check of the shipped code objects for the one hazard hipcc cannot see: the in-place MFMAs of net_mfma.hip /
-net_h3.hip are inline asm, so the compiler inserts no wait states between a VALU write of a VGPR and an MFMA that reads
-it as SrcA / SrcB / SrcC (2 wait states on gfx90a+; a v_mov zero-initialisation sunk next to the first MFMA of an
-accumulator chain gave 2e-3 errors in a 32-filter build of k_trunk_h3 before it was pinned).  Disassembles the gfx950 code
-object of every given .o (llvm-objdump) and fails if any VALU instruction writes a source register of a v_mfma within the
-two preceding wait states.  usage: python tools/check_mfma_hazards.py [objects...]   (default: the two trunk objects)
-Called by __graft_entry__.build()."""
+"""Static check of the shipped code objects for the hazards hipcc cannot see: the in-place MFMAs of the trunk kernels are
+inline asm, so the compiler inserts no wait states between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB /
+SrcC (2 wait states on gfx90a+; a v_mov zero-initialisation sunk next to the first MFMA of an accumulator chain gave 2e-3
+errors in a 32-filter build of k_trunk_h3 before it was pinned), nor between an MFMA and an early consumer of its result.
+
+Disassembles the gfx950 code object of every given .o (llvm-objdump) and fails if
+  (1) a VALU instruction writes a source register of a v_mfma within the two preceding wait states, or
+  (2) a non-MFMA instruction touches the result of an MFMA issued fewer than 12 wait states earlier (the 8-pass bound),
+along straight-line code AND ACROSS EVERY BRANCH EDGE: for each s_branch / s_cbranch_* the tail window of the branch's
+block is carried into the head of the target block (so a VALU write at the end of a loop body followed by the back-edge to
+an asm MFMA at the loop top is seen); fall-through edges are covered by the linear scan, which only resets at function
+symbols.  A taken branch is counted as ONE wait state (conservative: it costs more).  Indirect jumps (s_setpc) are not
+followed -- the trunk kernels have none (checked: the scan reports them).
+usage: python tools/check_mfma_hazards.py [objects...]   (default: the trunk objects).  Called by __graft_entry__.build()."""
 import glob
 import os
 import re
@@ -15,8 +22,29 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+WINDOW = 14
+# XDL write of a VGPR -> VALU / LDS / VMEM read or overwrite of it: passes + 3 (+1 on gfx950) wait states, i.e. 12 for an
+# 8-pass MFMA (cdna_hip_programming.md, inline-asm rules: "8-pass XDL: 12 states"), 8 for the 4-pass 16x16x32 f16
+RESULT_WAIT = 12
+
+
+def find_objdump():
+    """llvm-objdump of the ROCm toolchain: $ROCM_PATH / $HIP_PATH / /opt/rocm, then PATH."""
+    cands = []
+    for env in ("ROCM_PATH", "HIP_PATH"):
+        if os.environ.get(env):
+            cands.append(os.path.join(os.environ[env], "lib", "llvm", "bin", "llvm-objdump"))
+            cands.append(os.path.join(os.environ[env], "llvm", "bin", "llvm-objdump"))
+    cands += ["/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/llvm/bin/llvm-objdump"]
+    for c in cands:
+        if os.path.isfile(c) and os.access(c, os.X_OK):
+            return c
+    w = shutil.which("llvm-objdump")
+    if w:
+        return w
+    raise SystemExit("check_mfma_hazards: llvm-objdump not found (looked in $ROCM_PATH, $HIP_PATH, /opt/rocm and PATH): "
+                     "the MFMA hazard check of the inline-asm trunk kernels cannot run")
 
 
 def regs(tok):
@@ -29,71 +57,140 @@ def regs(tok):
     return out
 
 
-def check_object(path):
+class Ins:
+    __slots__ = ("addr", "mn", "ops", "opl", "ws", "dst", "func", "is_mfma", "target")
+
+    def __init__(self, addr, mn, ops, func, target):
+        self.addr, self.mn, self.ops, self.func, self.target = addr, mn, ops, func, target
+        self.opl = [o.strip() for o in ops.split(",")] if ops else []
+        self.is_mfma = mn.startswith("v_mfma") or mn.startswith("v_smfma")
+        # wait states this instruction puts between its predecessors and its successors: s_nop N = N + 1; an MFMA = 4,
+        # because the matrix pipe accepts one MFMA per 4 passes at best (16 cycles for v_mfma_f32_16x16x32_f16, measured:
+        # MI355X_MICROARCH.md cycle constants; the 32x32 and fp32 shapes take 8), so whatever follows an intervening
+        # MFMA issues at least 4 quad-cycles after the instruction in front of it; everything else = 1
+        self.ws = int(self.opl[0], 0) + 1 if mn == "s_nop" else (4 if self.is_mfma else 1)
+        self.dst = regs(self.opl[0]) if (mn.startswith("v_") and self.opl and not mn.startswith("v_cmp")) else set()
+
+    def text(self):
+        return "%s %s" % (self.mn, self.ops)
+
+
+def disassemble(path):
+    objdump = find_objdump()
     tmp = tempfile.mkdtemp(prefix="mfma_hz_")
     try:
         obj = os.path.join(tmp, os.path.basename(path))
         shutil.copy(path, obj)
-        subprocess.check_call([OBJDUMP, "--offloading", obj], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
+        subprocess.check_call([objdump, "--offloading", obj], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
         cos = [f for f in glob.glob(obj + ".*") if "gfx950" in f]
         assert cos, "no gfx950 code object in " + path
-        text = subprocess.check_output([OBJDUMP, "-d", cos[0]], text=True)
+        return subprocess.check_output([objdump, "-d", cos[0]], text=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    bad, n_mfma, func = [], 0, "?"
-    window = []   # (wait states this instruction provides, mnemonic, dest regs, text)
+
+
+def parse(text):
+    """-> list of functions, each a list of Ins in address order."""
+    funcs, cur, name = [], None, "?"
     for ln in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
         if m:
-            func, window = m.group(1), []
+            name, cur = m.group(1), []
+            funcs.append(cur)
             continue
-        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//", ln)
-        if not m:
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*// ([0-9A-Fa-f]+): ([0-9A-Fa-f]{8})", ln)
+        if not m or cur is None:
             continue
-        mn, ops = m.group(1), m.group(2)
-        opl = [o.strip() for o in ops.split(",")] if ops else []
-        if mn.startswith("v_mfma") or mn.startswith("v_smfma"):
-            n_mfma += 1
+        mn, ops, addr, enc = m.group(1), m.group(2), int(m.group(3), 16), int(m.group(4), 16)
+        target = None
+        if mn == "s_branch" or mn.startswith("s_cbranch"):
+            simm = enc & 0xFFFF
+            if simm >= 0x8000:
+                simm -= 0x10000
+            target = addr + 4 + 4 * simm
+        cur.append(Ins(addr, mn, ops, name, target))
+    return funcs
+
+
+def hazards(seq, first_consumer, last_producer):
+    """Scan `seq` (list of Ins); report hazards whose consumer index >= first_consumer and whose producer index <=
+    last_producer (None: any)."""
+    bad = []
+    for i in range(first_consumer, len(seq)):
+        c = seq[i]
+        lo = max(0, i - WINDOW)
+        if c.is_mfma:
             src = set()
-            for o in opl[1:4]:
+            for o in c.opl[1:4]:
                 src |= regs(o)
             dist = 0
-            for ws, pmn, dst, ptxt in reversed(window):
+            for j in range(i - 1, lo - 1, -1):
                 if dist >= 2:
                     break
-                if pmn.startswith("v_") and not pmn.startswith("v_mfma") and dst & src:
-                    bad.append("%s: `%s` writes a source of `%s %s` %d wait state(s) earlier" % (func, ptxt, mn, ops, dist))
-                dist += ws
-        elif opl and mn not in ("s_nop", "s_waitcnt", "s_barrier"):
+                p = seq[j]
+                if (last_producer is None or j <= last_producer) and p.mn.startswith("v_") and not p.is_mfma and p.dst & src:
+                    bad.append("%s: `%s` writes a source of `%s` %d wait state(s) earlier (0x%x -> 0x%x)"
+                               % (c.func, p.text(), c.text(), dist, p.addr, c.addr))
+                dist += p.ws
+        elif c.opl and c.mn not in ("s_nop", "s_waitcnt", "s_barrier"):
             # the other direction: a non-MFMA instruction touching the result of a recent MFMA (XDL write -> VALU / LDS /
             # VMEM access of the same VGPR needs up to 11 wait states for a 4-pass op).  hipcc handles this for its own
             # MFMAs; flag it for any MFMA so that the asm ones are covered.
             touched = set()
-            for o in opl:
+            for o in c.opl:
                 touched |= regs(o)
             dist = 0
-            for ws, pmn, dst, ptxt in reversed(window):
-                if dist >= 11:
+            for j in range(i - 1, lo - 1, -1):
+                if dist >= RESULT_WAIT:
                     break
-                if pmn.startswith("v_mfma") and dst & touched:
-                    bad.append("%s: `%s %s` touches the result of `%s` only %d wait state(s) later" % (func, mn, ops, ptxt, dist))
-                dist += ws
-        ws = 1
-        if mn == "s_nop":
-            ws = int(opl[0], 0) + 1
-        dst = regs(opl[0]) if (mn.startswith("v_") and opl and not mn.startswith("v_cmp")) else set()
-        window.append((ws, mn, dst, "%s %s" % (mn, ops)))
-        window = window[-14:]
-    return n_mfma, bad
+                p = seq[j]
+                if (last_producer is None or j <= last_producer) and p.is_mfma and p.dst & touched:
+                    bad.append("%s: `%s` touches the result of `%s` only %d wait state(s) later (0x%x -> 0x%x)"
+                               % (c.func, c.text(), p.text(), dist, p.addr, c.addr))
+                dist += p.ws
+    return bad
+
+
+def check_text(text):
+    """-> (number of MFMAs, hazard messages, number of branch edges checked, indirect jumps seen)"""
+    n_mfma, bad, edges, indirect = 0, [], 0, 0
+    for fn in parse(text):
+        n_mfma += sum(1 for x in fn if x.is_mfma)
+        indirect += sum(1 for x in fn if x.mn.startswith("s_setpc") or x.mn.startswith("s_swappc"))
+        bad += hazards(fn, 0, None)                      # straight-line code incl. every fall-through edge
+        index = {x.addr: k for k, x in enumerate(fn)}
+        for b, x in enumerate(fn):
+            if x.target is None or x.target not in index:
+                continue
+            t = index[x.target]
+            if t == b + 1:
+                continue                                 # same as the fall-through
+            tail = fn[max(0, b - WINDOW + 1): b + 1]      # ... up to and including the branch
+            head = fn[t: t + WINDOW]
+            edges += 1
+            bad += hazards(tail + head, len(tail), len(tail) - 1)
+    seen, uniq = set(), []
+    for m in bad:
+        if m not in seen:
+            seen.add(m)
+            uniq.append(m)
+    return n_mfma, uniq, edges, indirect
+
+
+def check_object(path):
+    n, bad, _, _ = check_text(disassemble(path))
+    return n, bad
 
 
 def main(paths):
     total, failed = 0, []
     for p in paths:
-        n, bad = check_object(p)
+        n, bad, edges, indirect = check_text(disassemble(p))
         total += n
         failed += bad
-        print("%s: %d MFMA instructions, %d VALU->MFMA hazards" % (os.path.relpath(p, ROOT), n, len(bad)))
+        print("%s: %d MFMA instructions, %d branch edges, %d hazards%s"
+              % (os.path.relpath(p, ROOT), n, edges, len(bad),
+                 "" if not indirect else " (%d indirect jumps NOT followed)" % indirect))
     per = {}
     for b in failed:
         per[b.split(":")[0]] = per.get(b.split(":")[0], 0) + 1
