@@ -58,13 +58,22 @@ def mflop_per_position(blocks, filters, board=8):
     return 2.0 * macs / 1e6
 
 
+# Planned wall-clock of the three `other_configs` legs at the planning rate (measured on the box: configs[3] ~45 s incl.
+# its staggered ramp, configs[4] ~20 s, the evaluation-cache run of configs[1] ~25 s); they are skipped when the run is
+# already past LEGS_DEADLINE seconds (a slow box, a cold start), so they can never push the headline out of the limit.
+OTHER_LEGS_SECONDS = 90.0
+LEGS_DEADLINE = 330.0
+
+
 def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_steps=1, cpu_budget=15.0,
-                    rate=PLANNING_RATE, startup=150.0):
+                    rate=PLANNING_RATE, startup=150.0, other_legs=OTHER_LEGS_SECONDS):
     """Wall-clock plan of one bench.py run on one MI355X (default workload): process start-up (the first
     `import torch` on a fresh box can take 2 minutes) + staggered ramp + (warmup + steps + profiled) steps +
-    CPU baseline."""
+    the secondary legs (scaled with the rate; none past LEGS_DEADLINE) + CPU baseline."""
     ramp = 0.5 * slots * min(stagger, 61) / 61.0 / rate          # half-full slots during the staggered start
-    return startup + ramp + (warmup + steps + profile_steps) * step_games / rate + cpu_budget + 10.0
+    head = startup + ramp + (warmup + steps + profile_steps) * step_games / rate
+    legs = other_legs * PLANNING_RATE / rate if head <= LEGS_DEADLINE else 0.0
+    return head + legs + cpu_budget + 10.0
 
 
 def cpu_baseline(net, sims, budget_s, evals_per_game):
@@ -91,7 +100,9 @@ def cpu_baseline(net, sims, budget_s, evals_per_game):
     if plies > 1:
         n, ev, th, dt = run(plies)
     out = {
-        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th, "kind": "port",
+        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th, "streams": cores, "kind": "port",
+        "cores_note": "`cores` = OpenMP threads that ran the sample (what the library reports), `streams` = independent "
+                      "self-play streams = hardware threads in this process's affinity mask; streams are dealt to the threads",
         "sample": "%d plies (%d network evals) of serial self-play on %d streams, stream s starting 58*s/%d random "
                   "plies into a game (phase-uniform: openings to endgames), %d plies each, 10x128 net fp32, %d "
                   "sims/move, %.1f s; scaled with %.1f plies/game (the engine's measured game length)"
@@ -164,6 +175,158 @@ def union_ms(spans):
     return float(total + (cur_e - cur_s))
 
 
+class Workload:
+    """The engines of one configuration on this rank: `lanes` independent slot groups, each a SearchEngine on its own
+    stream and host thread, sharing one set of packed weights; streaming self-play in steps (see the module docstring)."""
+
+    def __init__(self, pkg, torch, board, blocks, filters, sims, games, lanes, stagger, step_games, rank=0,
+                 precision=None, eval_cache=0, c_puct=1.0, temp_threshold=15):
+        import threading
+        self.pkg, self.torch, self.threading = pkg, torch, threading
+        self.board, self.blocks, self.filters, self.sims = board, blocks, filters, sims
+        self.games, self.lanes, self.step_games = games, max(1, lanes), step_games
+        assert games % self.lanes == 0 and step_games % self.lanes == 0
+        torch.manual_seed(42)
+        self.net = pkg.OthelloResNet(blocks, filters, board_size=board).eval()
+        self.ev = pkg.HipResNetEvaluator(self.net, precision=precision)
+        self.engs = [pkg.SearchEngine(games // self.lanes, sims, temperature_threshold=temp_threshold, c_puct=c_puct,
+                                      evaluator=self.ev, eval_cache_log2=eval_cache) for _ in range(self.lanes)]
+        self.dev = torch.cuda.current_device()
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.lanes)] if self.lanes > 1 else [None]
+        # history ring per lane: room for the largest step target (+10 % rebalancing, + the games finishing while the
+        # last rounds of a step are in flight) next to the games in flight
+        per_lane = games // self.lanes
+        hist = max(8 * per_lane, 2 * (int(1.1 * step_games) // self.lanes + 1) + 4 * per_lane)
+        self.all_lanes(lambda e, k: e.stream_begin(42 + 1000003 * (rank * self.lanes + k), stagger_rounds=stagger,
+                                                   hist_games=hist))
+
+    def all_lanes(self, fn):
+        """Run fn(engine, lane) for every lane -- each on its own stream and host thread -- and return the results."""
+        torch, lanes = self.torch, self.lanes
+        out, errors = [None] * lanes, []
+
+        def work(k):
+            try:
+                torch.cuda.set_device(self.dev)   # the HIP current device is per thread and new threads start on device 0
+                if self.streams[k] is None:
+                    out[k] = fn(self.engs[k], k)
+                else:
+                    with torch.cuda.stream(self.streams[k]):
+                        out[k] = fn(self.engs[k], k)
+            except BaseException as exc:   # a failing lane must fail the whole bench, not leave stale tuples behind
+                errors.append(exc)
+        if lanes == 1:
+            work(0)
+        else:
+            ths = [self.threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+        if errors:
+            raise errors[0]
+        return out
+
+    def play(self, target):
+        """One step's self-play: until >= target more games of this rank have finished -> (games, device tuple parts)."""
+        res = self.all_lanes(lambda e, k: e.stream_step(target // self.lanes))
+        return sum(r[0] for r in res), [e_.selfplay_device_tensors() for e_ in self.engs]
+
+    def counters(self):
+        tot = {}
+        for e_ in self.engs:
+            for k, v in e_.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def set_timing(self, on):
+        for e_ in self.engs:
+            e_.set_timing(on)
+
+    def profiled_steps(self, n_steps, step_fn):
+        """n_steps extra steps with the HIP-event hooks on -> the `prof` dict of the roofline objects."""
+        prof = {"evals": 0, "net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0, "union_ms": 0.0,
+                "wall_s": 0.0, "games": 0}
+        self.set_timing(True)
+        for _ in range(n_steps):
+            cp0 = self.counters()
+            t1 = time.time()
+            g = step_fn()
+            prof["wall_s"] += time.time() - t1
+            prof["games"] += g
+            prof["evals"] += self.counters()["evals"] - cp0["evals"]
+            spans = []
+            for e_ in self.engs:
+                for k, v in e_.kernel_time().items():
+                    prof[k] += v
+                spans.append(e_.net_spans())
+            prof["union_ms"] += union_ms(spans)
+        self.set_timing(False)
+        return prof
+
+    def roofline_numbers(self, prof):
+        """-> (achieved TFLOP/s over the union of the trunk launches, peak, kernel info from the library)."""
+        busy_s = prof["union_ms"] * 1e-3
+        alg = prof["evals"] * mflop_per_position(self.blocks, self.filters, self.board) * 1e6
+        achieved = alg / busy_s / 1e12 if busy_s > 0 else 0.0
+        peak = PEAK_F32_TFLOPS if self.ev.precision == "f32" else PEAK_F16_TFLOPS
+        info = self.ev.kernel_info(int(prof["evals"] / max(1, prof["net_launches"])))
+        return achieved, peak, info
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.engs, self.ev, self.net = [], None, None
+        import gc
+        gc.collect()
+
+
+def run_leg(pkg, torch, name, note, board, blocks, filters, sims, games, step_games, warmup, steps, c_puct=1.0,
+            temp_threshold=15, eval_cache=0, lanes=2, stagger=61):
+    """A short secondary measurement in the same process (N = 1 only, after the headline's timed region and profiled
+    step): the same streaming schedule on another BASELINE configuration -> a small dict for `other_configs`."""
+    t_leg = time.time()
+    w = Workload(pkg, torch, board, blocks, filters, sims, games, lanes, stagger, step_games, precision=None,
+                 eval_cache=eval_cache, c_puct=c_puct, temp_threshold=temp_threshold)
+    for _ in range(warmup):
+        w.play(step_games)
+    torch.cuda.synchronize()
+    c0, t0, n = w.counters(), time.time(), 0
+    for _ in range(steps):
+        n += w.play(step_games)[0]
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    c1 = w.counters()
+    st = {k: c1[k] - c0.get(k, 0) for k in c1}
+    prof = w.profiled_steps(1, lambda: w.play(step_games)[0])
+    achieved, peak, info = w.roofline_numbers(prof)
+    w.ev.check_saturation()
+    out = {
+        "config": name, "note": note, "value": round(n / dt, 2), "unit": "games/s", "games_timed": n,
+        "seconds_timed": round(dt, 2), "steps": steps, "warmup": warmup, "step_games": step_games,
+        "concurrent_games": games, "lanes": lanes,
+        "workload": "%dx%d, %d sims/move, %d-block x %d ResNet, c_puct %.2f, temperature threshold %d"
+                    % (board, board, sims, blocks, filters, c_puct, temp_threshold),
+        "evals_per_game": round(st["evals"] / max(1, st["games"]), 1),
+        "plies_per_game": round(st["plies"] / max(1, st["games"]), 2),
+        "kernel": info["kernel"], "dtype": w.ev.precision,
+        "roofline_frac": round(achieved / peak, 4), "achieved_tflops": round(achieved, 2), "peak_tflops": peak,
+        "frac_mfma_issue": round(achieved * info["issued_per_flop"] / peak, 4),
+        "mfma_flops_issued_per_algorithmic_flop": round(info["issued_per_flop"], 3),
+        "avg_launch_ms": round(prof["net_ms"] / max(1, prof["net_launches"]), 4),
+        "positions_per_launch": round(prof["evals"] / max(1, prof["net_launches"]), 1),
+        "net_time_share": round(prof["union_ms"] * 1e-3 / prof["wall_s"], 4) if prof["wall_s"] > 0 else None,
+        "tree_kernels_ms": round(prof["tree_ms"], 2),
+    }
+    if eval_cache:
+        hits = st.get("cache_hits", 0)
+        out["eval_cache"] = {"log2_entries": eval_cache, "hits": hits,
+                             "hit_rate": round(hits / max(1, hits + st["evals"]), 4),
+                             "positions_reached_per_game": round((hits + st["evals"]) / max(1, st["games"]), 1)}
+    w.close()
+    out["leg_seconds"] = round(time.time() - t_leg, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +350,11 @@ def main():
                          "games finish at a steady rate from the first timed step on (0: all at once)")
     ap.add_argument("--eval-cache", type=int, default=0,
                     help="log2 entries of the opt-in evaluation cache (0 = off; the headline number is measured with it OFF)")
+    ap.add_argument("--c-puct", type=float, default=1.0)
+    ap.add_argument("--temp-threshold", type=int, default=15)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short secondary legs (BASELINE configs[3], configs[4] and the evaluation-cache run of "
+                         "configs[1]) that a default single-GPU run of the headline workload appends as `other_configs`")
     ap.add_argument("--equal-shares", action="store_true",
                     help="N>1: every rank targets exactly --step-games per step instead of rate-proportional shares")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps after the timed region with HIP-event hooks on")
@@ -199,7 +367,9 @@ def main():
     args = ap.parse_args()
 
     t_start = time.time()
-    if not args.no_cpu_baseline:   # (re)build the CPU oracle now: no fork+exec once this process holds the GPU
+    # (re)build the CPU oracle now: no fork+exec once this process holds the GPU.  Only the single-process run times the
+    # CPU leg, so only it builds (eight ranks of an N>1 launch must not race one make target on a stale .so).
+    if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         oracle_lib.build()
@@ -219,16 +389,11 @@ def main():
         if rank == 0:
             print("[bench %6.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
 
-    torch.manual_seed(42)
-    net = pkg.OthelloResNet(args.blocks, args.filters, board_size=args.board).eval()
-    ev = pkg.HipResNetEvaluator(net, precision=args.precision)
-    import threading
     lanes = max(1, args.lanes)
-    assert args.games % lanes == 0 and args.step_games % lanes == 0
-    engs = [pkg.SearchEngine(args.games // lanes, args.sims, temperature_threshold=15, c_puct=1.0, evaluator=ev,
-                             eval_cache_log2=args.eval_cache) for _ in range(lanes)]
-    dev = torch.cuda.current_device()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else [None]
+    wl = Workload(pkg, torch, args.board, args.blocks, args.filters, args.sims, args.games, lanes, args.stagger,
+                  args.step_games, rank=rank, precision=args.precision, eval_cache=args.eval_cache, c_puct=args.c_puct,
+                  temp_threshold=args.temp_threshold)
+    net, ev, engs, dev = wl.net, wl.ev, wl.engs, wl.dev
 
     # OTHELLO_FORCE_DIST=1 under torchrun --nproc-per-node 1: run the RCCL calls of the N>1 path on a one-rank group
     use_dist = world > 1 or (dist.is_available() and dist.is_initialized())
@@ -250,53 +415,20 @@ def main():
     shares = [nominal] * world
 
     def rebalance(my_games, my_seconds):
-        if world == 1 or args.equal_shares:
+        if args.equal_shares or not use_dist:
             return
+        # (on a forced one-rank group the all-gather still runs -- it is the RCCL call an N>1 job makes -- and the
+        # shares stay [nominal])
         t = torch.tensor([my_games / max(my_seconds, 1e-6)], dtype=torch.float64, device="cpu" if gloo else "cuda")
         allr = torch.zeros(world, dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(allr, t)
         shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
 
-    def all_lanes(fn):
-        """Run fn(engine, lane) for every lane -- each on its own stream and host thread -- and return the results."""
-        out, errors = [None] * lanes, []
-
-        def work(k):
-            try:
-                torch.cuda.set_device(dev)   # the HIP current device is per thread and new threads start on device 0
-                if streams[k] is None:
-                    out[k] = fn(engs[k], k)
-                else:
-                    with torch.cuda.stream(streams[k]):
-                        out[k] = fn(engs[k], k)
-            except BaseException as exc:   # a failing lane must fail the whole bench, not leave stale tuples behind
-                errors.append(exc)
-        if lanes == 1:
-            work(0)
-        else:
-            ths = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
-            for t_ in ths:
-                t_.start()
-            for t_ in ths:
-                t_.join()
-        if errors:
-            raise errors[0]
-        return out
-
-    # history ring per lane: room for the largest step target (+10 % rebalancing, + the games finishing while the
-    # last rounds of a step are in flight) next to the games in flight
-    per_lane = args.games // lanes
-    hist = max(8 * per_lane, 2 * (int(1.1 * args.step_games) // lanes + 1) + 4 * per_lane)
-    all_lanes(lambda e, k: e.stream_begin(42 + 1000003 * (rank * lanes + k), stagger_rounds=args.stagger,
-                                          hist_games=hist))
-
     def step():
         """-> (games this rank finished, replay samples of the whole job after the exchange)"""
         mine = shares[rank]
         t_play = time.time()
-        res = all_lanes(lambda e, k: e.stream_step(mine // lanes))
-        games = sum(r[0] for r in res)
-        parts = [e_.selfplay_device_tensors() for e_ in engs]
+        games, parts = wl.play(mine)
         t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
             st, pi, z = ([p_[j].cpu() if gloo else p_[j] for p_ in parts] for j in range(3))   # one part per lane
@@ -309,8 +441,7 @@ def main():
 
     all_launch = {"ms": 0.0, "n": 0}
     if args.hooks_always:
-        for e_ in engs:
-            e_.set_timing(True)
+        wl.set_timing(True)
 
     def tally_launches():
         if args.hooks_always:
@@ -319,13 +450,7 @@ def main():
                 all_launch["ms"] += kt["net_ms"]
                 all_launch["n"] += kt["net_launches"]
 
-    def counters():
-        tot = {}
-        for e_ in engs:
-            for k, v in e_.counters().items():
-                tot[k] = tot.get(k, 0) + v
-        return tot
-
+    counters = wl.counters
     beat("setup done (%dx%d net, %d slots in %d lanes, %d sims); warm-up: %d steps of %d games"
          % (args.blocks, args.filters, args.games, lanes, args.sims, args.warmup, args.step_games))
     barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
@@ -361,57 +486,43 @@ def main():
     prof = {"evals": 0, "net_ms": 0.0, "net_launches": 0, "tree_ms": 0.0, "tree_launches": 0, "union_ms": 0.0,
             "wall_s": 0.0, "games": 0}
     if args.profile_steps > 0:
-        for e_ in engs:
-            e_.set_timing(True)
-        for _ in range(args.profile_steps):
-            cp0 = counters()
-            t1 = time.time()
-            g, _ = step()
+        def prof_step():
+            g_ = step()[0]
             tally_launches()
-            prof["wall_s"] += time.time() - t1
-            prof["games"] += g
-            cp1 = counters()
-            prof["evals"] += cp1["evals"] - cp0["evals"]
-            spans = []
-            for e_ in engs:
-                for k, v in e_.kernel_time().items():
-                    prof[k] += v
-                spans.append(e_.net_spans())
-            prof["union_ms"] += union_ms(spans)
-        for e_ in engs:
-            e_.set_timing(False)
+            return g_
+        prof = wl.profiled_steps(args.profile_steps, prof_step)
+        if args.hooks_always:
+            wl.set_timing(True)
         beat("profiled step: %d games in %.2f s, %d trunk launches, busy %.0f ms"
              % (prof["games"], prof["wall_s"], prof["net_launches"], prof["union_ms"]))
+    ev.check_saturation()   # the clamp of the fp16-split trunk, surfaced: never a silent deviation from the reference
 
     if rank == 0:
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes over THIS command's own launch shape
         # (two lanes, ~1 900 positions per trunk launch): profiles/r03_bench_traffic.json, written by tools/bench_pmc.sh
         traffic, tree_traffic, traffic_basis = None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_bench_traffic.json")) as f:
+            tfile = next(f_ for f_ in ("r04_bench_traffic.json", "r03_bench_traffic.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 tj = json.load(f)
             tk = tj["kernels"].get("trunk") or tj["kernels"]["k_trunk16"]
             traffic = tk["traffic_bytes_per_launch"]
             tree_traffic = tj["kernels"]["k_tree"]["traffic_bytes_per_launch"]
-            traffic_basis = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `%s` (profiles/r03_bench_traffic.json): "
+            traffic_basis = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `%s` (profiles/%s): "
                              "kernel %s, %.0f positions per trunk launch there; gfx950 FETCH_SIZE x2 correction applied to the "
-                             "16 B/lane weight reads" % (tj["command"], tk["kernel"], tk["positions_per_launch"]))
+                             "16 B/lane weight reads" % (tj["command"], tfile, tk["kernel"], tk["positions_per_launch"]))
         except Exception:
             pass
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
         # lanes overlap on the device, so FLOPs are divided by the time during which the kernel was running at all.
         net_s = prof["union_ms"] * 1e-3
-        flops = prof["evals"] * mflop_per_position(args.blocks, args.filters, args.board) * 1e6
-        achieved = flops / net_s / 1e12 if net_s > 0 else 0.0
+        achieved, peak, kinfo = wl.roofline_numbers(prof)
         prec = ev.precision
-        # MFMA FLOPs the trunk issues per algorithmic FLOP: 3 products of the fp16x3 split, minus the tiles whose
-        # source row is zero padding (1/12 of the conv work is skipped by the shipped kernel)
-        wide = args.filters == 128 and args.board == 8     # k_trunk16 skips the all-padding tiles (1/12 of the work)
-        # launches of > 256 positions of the wide f16x3 network run the 1-D Winograd F(2,3) trunk (net_wino.hip: 4 MFMAs per 2
-        # outputs instead of 6, no row skip) unless OTH_WINO=0 keeps them on the direct kernel k_trunk16
-        wino = wide and prec == "f16x3" and os.environ.get("OTH_WINO", "1") != "0"
-        issued = (3.0 if prec == "f16x3" else 1.0) * ((2.0 / 3.0 if wino else 11.0 / 12.0) if (prec != "f32" and wide) else 1.0)
-        peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
+        # which trunk kernel ran and how many MFMA FLOPs it issues per algorithmic FLOP come from the LIBRARY
+        # (oth_net_kernel_info follows the dispatch of oth_net_forward_bits), not from a re-derivation here
+        issued = kinfo["issued_per_flop"]
+        wide = args.filters == 128 and args.board == 8 and prec != "f32"   # the configuration the PMC traffic file is for
         evals_per_game = stats["evals"] / max(1, stats["games"])
         out = {
             "metric": "self-play games/sec (%dx%d, %d MCTS sims/move)" % (args.board, args.board, args.sims),
@@ -438,11 +549,14 @@ def main():
                         "full across steps; staggered start over %d ply rounds during warm-up)" % (args.step_games, args.stagger),
                 "games_timed": total_games, "concurrent_games_per_gpu": args.games,
                 "weights": "seeded random init (torch.manual_seed(42)), eval mode",
-                "c_puct": 1.0, "temperature_threshold": 15, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
+                "c_puct": args.c_puct, "temperature_threshold": args.temp_threshold, "dirichlet": "alpha 0.3 eps 0.25 (no effect on this search)",
                 "parallelism": "dp%d: games sharded, %s" % (
                     world, "single GPU" if not use_dist else
                     ("gloo all-gather of replay tuples per step on host copies (REHEARSAL: several ranks share one GPU; "
-                     "not a multi-GPU measurement)" if gloo else "RCCL all-gather of replay tuples per step")),
+                     "not a multi-GPU measurement)" if gloo else
+                     "RCCL all-gather of replay tuples per step" + ("" if world > 1 else
+                     " (one-rank group, OTHELLO_FORCE_DIST: exercises the RCCL calls of the N>1 path, not a multi-GPU "
+                     "measurement)"))),
                 "lanes_per_gpu": lanes,
                 "step_targets_last_step": ("equal" if world == 1 or args.equal_shares else
                                            "proportional to each rank's measured rate in the previous step "
@@ -455,16 +569,14 @@ def main():
                 "timing_hooks_in_timed_region": bool(args.hooks_always),
             },
             "roofline": {
-                "kernel": ("k_trunk_f32 (fused ResNet forward, fp32 MFMA)" if prec == "f32" else
-                           "k_trunk_w (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions)" if wino else
-                           "k_trunk16 (fused ResNet forward)" if wide else
-                           "k_trunk_h3 (fused ResNet forward, one wave per position)"),
+                "kernel": kinfo["kernel"],
                 "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic if wide and prec != "f32" else None,
-                "flops_basis": "ALGORITHMIC FLOPs of the direct 3x3 convolutions (378.03 MFLOP per position), whatever the "
-                               "kernel issues: the Winograd trunk issues 2.0 MFMA FLOPs per algorithmic FLOP, the direct "
-                               "one 2.75",
+                "frac": round(achieved / peak, 4), "traffic": traffic if wide else None,
+                "flops_basis": "ALGORITHMIC FLOPs of the direct 3x3 convolutions (%.2f MFLOP per position), whatever the "
+                               "kernel issues: this kernel issues %.3f MFMA FLOPs per algorithmic FLOP (8x8, 128 filters: "
+                               "the Winograd trunk 2.0, the direct one 2.75)"
+                               % (mflop_per_position(args.blocks, args.filters, args.board), issued),
                 "traffic_basis": traffic_basis,
                 "algorithmic_bytes_per_launch": round(prof["evals"] / max(1, prof["net_launches"]) * (24 + 4 * (args.board ** 2 + 2))),
                 "measured_on": "%d profiled step(s) after the timed region (HIP-event hooks on, %d games, %.2f s)"
@@ -504,6 +616,41 @@ def main():
         }
         # evidence first: if the CPU leg were to be killed the measured line is already on stderr
         print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)
+        # ---- short secondary legs: the other single-GPU BASELINE configurations, driver-run in the same process --------
+        headline = (args.board, args.blocks, args.filters, args.sims, args.games, args.eval_cache, args.precision) == \
+            (8, 10, 128, 50, 4096, 0, None)
+        if headline and not use_dist and not args.no_other_configs and time.time() - t_start > LEGS_DEADLINE:
+            out["other_configs"] = [{"skipped": "the run was already %.0f s old (deadline %.0f s)"
+                                                % (time.time() - t_start, LEGS_DEADLINE)}]
+        elif headline and not use_dist and not args.no_other_configs:
+            wl.close()
+            engs = []
+            legs = (
+                dict(name="configs[3]", note="BASELINE configs[3]: 400 sims/move, c_puct 1.5, temperature threshold 20 "
+                     "(deep trees); 2048 concurrent games so that the staggered ramp fits the leg",
+                     board=8, blocks=10, filters=128, sims=400, games=2048, step_games=256, warmup=2, steps=4,
+                     c_puct=1.5, temp_threshold=20),
+                dict(name="configs[4]", note="BASELINE configs[4]: 6x6 board, 25 sims/move, 5x64 network -- 6x6 RULES "
+                     "PARITY UNPINNED (the reference implements no 6x6 game; network pinned by its own outputs, rules checked "
+                     "against the 6x6 build of the CPU oracle only)",
+                     board=6, blocks=5, filters=64, sims=25, games=4096, step_games=32768, warmup=3, steps=4),
+                dict(name="configs[1] + eval cache", note="configs[1] with the opt-in evaluation cache ON (2^22 entries per "
+                     "lane): a transposition table of network outputs, every (state, pi, z) bit-identical, but network "
+                     "evaluations are SKIPPED on hits -- NOT the headline configuration, never `value`",
+                     board=8, blocks=10, filters=128, sims=50, games=4096, step_games=1536, warmup=5, steps=8,
+                     eval_cache=22),
+            )
+            out["other_configs"] = []
+            for leg in legs:
+                beat("leg %s ..." % leg["name"])
+                try:
+                    out["other_configs"].append(run_leg(pkg, torch, **leg))
+                    beat("leg %s: %.1f games/s, frac %.3f, %.0f s" % (leg["name"], out["other_configs"][-1]["value"],
+                                                                      out["other_configs"][-1]["roofline_frac"],
+                                                                      out["other_configs"][-1]["leg_seconds"]))
+                except Exception as exc:   # a failing leg must not take the headline down with it
+                    out["other_configs"].append({"config": leg["name"], "error": repr(exc)})
+            print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1 and args.board == 8:   # the oracle's CPU network is 8x8 only
             try:
                 out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget, evals_per_game)

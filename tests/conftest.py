@@ -12,13 +12,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Multi-rank rehearsal of bench.py's N>1 path (tests/test_gpu_multirank.py): FOUR ranks sharing GPU 0 over gloo (the
-# GPU box admits at most 6 processes on its card: 4 ranks + this pytest process; the world-size-8 form of the exchange
-# step runs on CPU tensors in tests/test_distributed_cpu.py).
-# The children must be started BEFORE this process touches the GPU (a GPU-initialised process must not fork+exec on
-# this pool), so they are launched here, at session start of a `-m gpu` run, and the test only collects the result.
-REHEARSAL = {"proc": None, "out": None, "err": None}
-REHEARSAL_RANKS = 4
+# Child processes of a `-m gpu` session (tests/gpu_children.py runs them one after the other): the four-rank gloo
+# rehearsal of bench.py's N>1 path (four ranks sharing GPU 0: the box admits 6 processes on its card; the world-size-8
+# form of the exchange step runs on CPU tensors in tests/test_distributed_cpu.py), then the SAME path and the
+# trainer-facing DistributedSelfPlayWorker on a one-rank nccl (= RCCL) group.  The launcher must be started BEFORE this
+# process touches the GPU (a GPU-initialised process must not fork+exec on this pool), so it is started here, at session
+# start; it never initialises the GPU itself, and the tests only collect its results.
+CHILDREN = {"proc": None, "dir": None, "ranks": 4}
 
 
 def _wants_gpu(config):
@@ -43,38 +43,50 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     if not _wants_gpu(session.config) or os.environ.get("OTHELLO_NO_REHEARSAL"):
         return
-    out = tempfile.NamedTemporaryFile("w+", suffix=".json", delete=False)
-    err = tempfile.NamedTemporaryFile("w+", suffix=".err", delete=False)
-    import socket
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    env = dict(os.environ)
-    env.update({"OTHELLO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
-    REHEARSAL["ranks"] = REHEARSAL_RANKS
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(REHEARSAL_RANKS),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(REHEARSAL_RANKS), "--steps", "2", "--warmup", "1", "--games", "64", "--step-games", "32",
-           "--sims", "6",
-           "--blocks", "2", "--filters", "16", "--stagger", "8", "--profile-steps", "1", "--no-cpu-baseline"]
-    REHEARSAL["proc"] = subprocess.Popen(cmd, stdout=out, stderr=err, env=env, cwd=ROOT)
-    REHEARSAL["out"], REHEARSAL["err"] = out.name, err.name
+    CHILDREN["dir"] = tempfile.mkdtemp(prefix="oth_gpu_children_")
+    CHILDREN["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_children.py"), CHILDREN["dir"]],
+                                        cwd=ROOT, start_new_session=True)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    p = REHEARSAL["proc"]
-    if p is not None and p.poll() is None:   # never leave ranks behind
-        p.terminate()
-        try:
-            p.wait(timeout=20)
-        except Exception:
-            p.kill()
+    p = CHILDREN["proc"]
+    if p is not None and p.poll() is None:   # never leave ranks behind: end the launcher's own process group
+        import signal
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=20)
+                break
+            except Exception:
+                pass
 
 
 @pytest.fixture(scope="session")
-def rehearsal():
-    return REHEARSAL
+def children():
+    """stage(name, timeout) -> (rc, stdout, stderr) of a stage of tests/gpu_children.py, waiting for it to finish."""
+    import time
+
+    def stage(name, timeout=1200):
+        assert CHILDREN["proc"] is not None, "the child processes were not started (run with `-m gpu`)"
+        rc_file = os.path.join(CHILDREN["dir"], name + ".rc")
+        t0 = time.time()
+        while not os.path.exists(rc_file):
+            assert time.time() - t0 < timeout, "stage %s did not finish in %d s" % (name, timeout)
+            assert CHILDREN["proc"].poll() is None or os.path.exists(rc_file), "the launcher exited without running " + name
+            time.sleep(0.5)
+        time.sleep(0.2)
+        rd = lambda ext: open(os.path.join(CHILDREN["dir"], name + ext)).read()   # noqa: E731
+        return int(rd(".rc")), rd(".out"), rd(".err")
+    def wait_all(timeout=1500):
+        """Block until every child stage has ended (tests that read device-wide state, e.g. free memory)."""
+        if CHILDREN["proc"] is not None:
+            CHILDREN["proc"].wait(timeout=timeout)
+    stage.ranks = CHILDREN["ranks"]
+    stage.wait_all = wait_all
+    return stage
 
 
 @pytest.fixture(scope="session")

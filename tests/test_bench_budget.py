@@ -29,12 +29,14 @@ def test_driver_command_fits_the_limit():
     cpu = _default("cpu-budget")
     # the driver's round-end command, with 150 s allowed for process start-up on a fresh box
     t = b.planned_seconds(20, 5, step_games, slots, stagger, profile, cpu)
-    assert t <= 300.0, "driver command planned at %.0f s (limit 600 s, target <= 300 s)" % t
+    # (round 4: + ~90 s for the three `other_configs` legs -- configs[3], configs[4], configs[1] with the evaluation cache)
+    assert t <= 400.0, "driver command planned at %.0f s (limit 600 s, target <= 400 s)" % t
+    assert b.OTHER_LEGS_SECONDS <= 100.0 and b.LEGS_DEADLINE + 2 * b.OTHER_LEGS_SECONDS + 30 <= 600.0
     # and at half the planning rate it still finishes inside the hard limit
     assert b.planned_seconds(20, 5, step_games, slots, stagger, profile, cpu, rate=b.PLANNING_RATE / 2) < 600.0
     # no-flag defaults: minutes, not tens of minutes
     t0 = b.planned_seconds(int(_default("steps")), int(_default("warmup")), step_games, slots, stagger, profile, cpu)
-    assert t0 <= 260.0
+    assert t0 <= 350.0
     # N>1 does the same per-rank work per step (weak scaling) plus the all-gather (~0.13 GB per rank per step):
     # the plan per rank is unchanged
     assert step_games * 63e3 * 8 / 50e9 < 0.5    # 8 ranks' tuples over xGMI at a pessimistic 50 GB/s: < 0.5 s per step

@@ -1,8 +1,17 @@
-"""BASELINE.json configs[2] (N-GPU data-parallel self-play with an all-gather of the replay tuples) kept from
-rotting while no multi-GPU node is available: bench.py's N>1 path run by FOUR ranks sharing GPU 0, collectives over
-gloo (RCCL needs one GPU per rank; the box admits six processes on its card, so eight ranks cannot share it -- the
-world-size-8 exchange step runs on CPU tensors in tests/test_distributed_cpu.py).  The ranks are started by tests/conftest.py at session start, before this
-process initialises the GPU; this test waits for them and checks the JSON line."""
+"""BASELINE.json configs[2] (N-GPU data-parallel self-play with an RCCL all-gather of the replay tuples) kept from
+rotting while no multi-GPU node is available.  Three child stages, run one after the other by tests/gpu_children.py (started
+by tests/conftest.py at session start, before this process initialises the GPU):
+
+* ``rehearsal``    bench.py's N>1 path by FOUR ranks sharing GPU 0, collectives over gloo (RCCL needs one GPU per rank; the
+                   box admits six processes on its card, so eight ranks cannot share it -- the world-size-8 exchange step
+                   runs on CPU tensors in tests/test_distributed_cpu.py);
+* ``rccl_bench``   the SAME code path on a ONE-RANK nccl (= RCCL) group (OTHELLO_FORCE_DIST=1, torch.distributed.run
+                   --nproc-per-node 1): the exchange's persistent buffers, the rate all-gather, the device barrier and the
+                   final all-reduces run on device tensors through RCCL, as they will on an 8-GPU node;
+* ``rccl_worker``  tests/rccl_one_rank_check.py: all_gather_replay with two lane parts over six steps, and
+                   DistributedSelfPlayWorker.execute_episodes_tensors with a shrinking second call, on that backend.
+
+These tests wait for the stages and check what they printed."""
 import json
 
 import pytest
@@ -10,26 +19,52 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_multi_rank_rehearsal(rehearsal):
-    p = rehearsal["proc"]
-    assert p is not None, "the rehearsal was not started (run with `-m gpu`)"
-    rc = p.wait(timeout=900)
-    err = open(rehearsal["err"]).read()
-    assert rc == 0, "rehearsal failed (rc %d):\n%s" % (rc, err[-3000:])
-    lines = [ln for ln in open(rehearsal["out"]).read().splitlines() if ln.startswith("{")]
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 must print exactly one JSON line, got %d" % len(lines)
-    d = json.loads(lines[0])
-    w = rehearsal["ranks"]
+    return json.loads(lines[0])
+
+
+def _check_small_bench(d, w, err):
     assert d["n_gpus"] == w and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "games/s" and d["value"] > 0 and d["higher_is_better"] is True
     cfg = d["config"]
     assert cfg["games_timed"] >= 2 * w * 29           # every rank's games are counted (shares within +-10 % of 32)
     assert "dp%d" % w in cfg["parallelism"] and "all-gather" in cfg["parallelism"]
-    assert "REHEARSAL" in cfg["parallelism"] and "gloo" in cfg["parallelism"]    # never reads as an RCCL measurement
     # the all-gathered tuple count of the last step covers all ranks: ~60 plies per game, ~32 games per rank
     assert cfg["samples_last_step"] > w * 29 * 40
     assert d["roofline"]["launches"] > 0 and d["cpu_baseline"] is None
+    assert d["roofline"]["kernel"].startswith("k_trunk_f32")      # the 2x16 network: named by the library itself
     rr = d["roofline_rollout"]           # the tree kernel against the HBM roofline, measured live in the profiled step
     assert rr["bound"] == "hbm" and rr["unit"] == "GB/s" and rr["achieved"] > 0 and rr["launches"] > 0
     assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-4
     assert "step 2/2" in err                            # heartbeat lines on stderr
+
+
+def test_bench_multi_rank_rehearsal(children):
+    rc, out, err = children("rehearsal")
+    assert rc == 0, "rehearsal failed (rc %d):\n%s" % (rc, err[-3000:])
+    d = _json_line(out)
+    _check_small_bench(d, children.ranks, err)
+    par = d["config"]["parallelism"]
+    assert "REHEARSAL" in par and "gloo" in par         # never reads as an RCCL measurement
+
+
+def test_bench_n_gt_1_path_on_rccl_one_rank(children):
+    """bench.py's N>1 code on RCCL: one rank is all this pool offers, but the calls are the ones an 8-GPU node makes."""
+    rc, out, err = children("rccl_bench")
+    assert rc == 0, "one-rank RCCL bench failed (rc %d):\n%s" % (rc, err[-3000:])
+    d = _json_line(out)
+    _check_small_bench(d, 1, err)
+    par = d["config"]["parallelism"]
+    assert "RCCL all-gather" in par and "REHEARSAL" not in par and "gloo" not in par
+    assert "one-rank group" in par                      # and never reads as a multi-GPU measurement either
+
+
+def test_distributed_worker_and_exchange_on_rccl_one_rank(children):
+    rc, out, err = children("rccl_worker")
+    assert rc == 0, "one-rank RCCL worker check failed (rc %d):\n%s" % (rc, err[-3000:])
+    d = _json_line(out)
+    assert d["ok"] is True and d["backend"] == "nccl" and d["world"] == 1 and d["exchange_steps"] == 6
+    calls = d["worker_calls"]
+    assert len(calls) == 3 and calls[1] < calls[0]      # the second call's tuple count shrank

@@ -996,12 +996,11 @@ def test_selfplay_full_size_properties(pkg):
         _check_replay_consistency(pkg, st[a:a + L], pi[a:a + L], z[a:a + L], np.array([L]), 15, onehot_late=False)
 
 
-def test_no_device_memory_growth(pkg, rehearsal):
+def test_no_device_memory_growth(pkg, children):
     """Repeated runs of different sizes on one engine, plus engine / evaluator create-destroy cycles, must not
     leak device memory (hipMemGetInfo before and after; the library allocates with hipMalloc, outside torch's
     caching allocator)."""
-    if rehearsal["proc"] is not None:   # the two-rank rehearsal shares this GPU: device-wide free memory moves with it
-        rehearsal["proc"].wait(timeout=900)
+    children.wait_all()   # the child stages (rehearsal ranks, RCCL checks) share this GPU: device-wide free memory moves with them
     torch.manual_seed(2)
     net = pkg.OthelloResNet(2, 16).eval()
     w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=5, temperature_threshold=6,

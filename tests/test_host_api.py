@@ -202,7 +202,8 @@ def test_no_mfma_hazards_in_built_objects():
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f) for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o")]
+    objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f)
+            for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o", "net_f32.o")]
     if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("object files / llvm-objdump not present (the .o files do not travel to the GPU box)")
     spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
@@ -210,7 +211,7 @@ def test_no_mfma_hazards_in_built_objects():
     spec.loader.exec_module(mod)
     for o in objs:
         n, bad = mod.check_object(o)
-        assert n > 500 and not bad, bad[:3]
+        assert n > 200 and not bad, bad[:3]
 
 
 def test_hazard_checker_sees_across_branch_edges():
@@ -263,3 +264,8 @@ def test_hazard_checker_sees_across_branch_edges():
     assert mod.check_text(asm([mfma, other, other, other, ("v_mov_b32_e32", "v30, v1")]))[1] == []
     assert len(mod.check_text(asm([mfma, other, other, ("v_mov_b32_e32", "v30, v1")]))[1]) == 1
     assert mod.find_objdump()
+    # (4) rule 3: a packed-fp32 op taking a source's HIGH dword for its low lane (the round-3 value-head defect)
+    pk = lambda sel: asm([("v_pk_fma_f32", "v[4:5], v[22:23], v[14:15], v[4:5] " + sel)])   # noqa: E731
+    assert len(mod.check_text(pk("op_sel:[0,1,0]"))[1]) == 1
+    assert mod.check_text(pk("op_sel_hi:[1,0,1]"))[1] == [] and mod.check_text(pk(""))[1] == []
+    assert mod.check_text(asm([("v_pk_fma_f16", "v4, v22, v14, v4 op_sel:[0,1,0]")]))[1] == []   # 16-bit packed ops: not meant

@@ -7,7 +7,12 @@ errors in a 32-filter build of k_trunk_h3 before it was pinned), nor between an 
 Disassembles the gfx950 code object of every given .o (llvm-objdump) and fails if
   (1) a VALU instruction writes a source register of a v_mfma within the two preceding wait states, or
   (2) a non-MFMA instruction touches the result of an MFMA issued fewer than 12 wait states earlier (the 8-pass bound),
-along straight-line code AND ACROSS EVERY BRANCH EDGE: for each s_branch / s_cbranch_* the tail window of the branch's
+  (3) any packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) selects the HIGH dword
+      of a source pair for its LOW lane (`op_sel:[..1..]`): on gfx950 that operand form returns wrong results now and then
+      when two waves share a SIMD (round 4: tools/probes/probe_pk_opsel.hip, heads_batch4_variants.sh -- the cause of the
+      value-head errors of round 3).  hipcc's SLP vectoriser emits it for broadcast operands, so the library is built with
+      -fno-slp-vectorize and its own packed arithmetic (net_epilogue.h) uses plain pairs only,
+(1) and (2) along straight-line code AND ACROSS EVERY BRANCH EDGE: for each s_branch / s_cbranch_* the tail window of the branch's
 block is carried into the head of the target block (so a VALU write at the end of a loop body followed by the back-edge to
 an asm MFMA at the loop top is seen); fall-through edges are covered by the linear scan, which only resets at function
 symbols.  A taken branch is counted as ONE wait state (conservative: it costs more).  Indirect jumps (s_setpc) are not
@@ -151,10 +156,26 @@ def hazards(seq, first_consumer, last_producer):
     return bad
 
 
+PK_F32 = re.compile(r"^v_pk_(fma|mul|add)_f32$|^v_pk_mov_b32$")
+
+
+def pk_opsel_hi_to_lo(fn):
+    """Rule (3): packed-fp32 instructions whose op_sel routes a source's high dword to the low lane."""
+    bad = []
+    for x in fn:
+        if PK_F32.match(x.mn):
+            m = re.search(r"op_sel:\[([01,]+)\]", x.ops)
+            if m and "1" in m.group(1):
+                bad.append("%s: `%s` selects a source's HIGH dword for the low lane (unreliable on gfx950 with two waves "
+                           "per SIMD) (0x%x)" % (x.func, x.text(), x.addr))
+    return bad
+
+
 def check_text(text):
     """-> (number of MFMAs, hazard messages, number of branch edges checked, indirect jumps seen)"""
     n_mfma, bad, edges, indirect = 0, [], 0, 0
     for fn in parse(text):
+        bad += pk_opsel_hi_to_lo(fn)
         n_mfma += sum(1 for x in fn if x.is_mfma)
         indirect += sum(1 for x in fn if x.mn.startswith("s_setpc") or x.mn.startswith("s_swappc"))
         bad += hazards(fn, 0, None)                      # straight-line code incl. every fall-through edge
@@ -203,5 +224,6 @@ def main(paths):
 
 if __name__ == "__main__":
     args = sys.argv[1:] or [os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "csrc", f)
-                            for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o")]
+                            for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o", "net_f32.o", "engine.o",
+                                      "replay_ops.o", "rules_api.o", "net.o")]
     sys.exit(main(args))
