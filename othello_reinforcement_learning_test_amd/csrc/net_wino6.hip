@@ -10,10 +10,14 @@
 // -- 8 x 6 = 48 pairs = three lane groups -- and the tile column j = 0..2 selects the ACCUMULATOR: N-tile nt = 3*lg + j,
 // nine N-tiles x four transformed taps = 36 accumulators per wave.  The x neighbours in(2j-1), in(2j+2) of the input
 // transform are therefore other registers of the SAME lane: no DPP, no edge masks (j = 0 and j = 2 are compile-time), and
-// all nine N-tiles are full (48 = 3 x 16).  The transformed operand V lives in LDS as [tile = (position, row, j)][xi][hi 64
-// x f16 | lo 64 x f16] = 144 KB for eight positions; the 16-byte slot of a lane's k-group is XOR-swizzled with twice the low
-// bits of the (position, row) index, so that the lanes of every ds_read_b128 service group cover all 64 banks for all
-// three row taps (see "V addressing" below).  Every weight is loaded once per EIGHT positions (k_trunk_h3: once per two).
+// all nine N-tiles are full (48 = 3 x 16).  The transformed operand V lives in LDS in FRAGMENT ORDER (round 4):
+// [lane group 3][k-group g4 4][j 3][xi 4][k-step 2][hi | lo][column c 16][16 B] = 144 KB for eight positions, so that a
+// ds_read_b128 of (lane group, j, xi, k-step, half) reads four 256-byte runs, one per k-group, 12 KB apart: what the LDS
+// serves at full rate (tools/probes/probe_w6_step.hip: the round-3 image -- tile x 3 KB with an XOR-swizzled slot, conflict-
+// free by the lane-group model of the guide -- cost 4.9 cycles per MFMA in the convolution, 28 % of it in the kernel).  A row
+// tap is a shift of the column by one (its 16-byte slot; column 0 / 15 take theirs from the neighbouring lane group's block);
+// lanes whose source row is off the board read a 12 KB block of zeros.  Every weight is loaded once per EIGHT positions
+// (k_trunk_h3: once per two).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,10 +36,14 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int k6F = 64, k6BS = 6, k6Cells = 36, k6NP = 37, k6TP = 8;
 constexpr int k6NT = 9;                         // N-tiles of a wave: 3 lane groups x 3 tile columns
-constexpr int k6TileBytes = 1024;               // one tile: 4 xi x (128 B hi + 128 B lo)
-constexpr int k6VBytes = k6TP * 18 * k6TileBytes;   // 147456
-constexpr int k6ZeroOff = k6VBytes;             // 4 KB of zeros: the source of out-of-board rows (any j, xi, k-step)
-constexpr int k6Lds = k6VBytes + 4096;          // 151552
+constexpr int k6RunBytes = 256;                 // 16 columns x 16 B: what one k-group of a ds_read_b128 reads
+constexpr int k6PlaneBytes = 3 * 4 * 2 * 2 * k6RunBytes;   // (j, xi, k-step, half) runs of one (lane group, k-group): 12288
+constexpr int k6LgBytes = 4 * k6PlaneBytes;     // 49152
+constexpr int k6VBytes = 3 * k6LgBytes;         // 147456
+constexpr int k6ZeroOff = k6VBytes;             // a plane of zeros: the source of out-of-board rows (any j, xi, k-step, half)
+constexpr int k6Lds = k6VBytes + k6PlaneBytes;  // 159744 of the CU's 163840
+// byte offset of the run (j, xi, k-step, half) inside a plane
+__host__ __device__ constexpr int k6_run(int j, int xi, int kk, int half) { return (((j * 4 + xi) * 2 + kk) * 2 + half) * k6RunBytes; }
 constexpr float k6ActScale = 16.0f;             // activations and residual are carried x 2^4
 constexpr float k6Clamp = 30000.0f;             // |V| <= 2 x activation must stay in the f16 range: activations <= 1875
 constexpr int k6Groups = 6;                     // (row tap d, k-step kk of 32 input channels): g = 2*d + kk
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
             dst[q] = t;
         }
     }
-    ((uint4*)(lds + k6ZeroOff))[tid] = make_uint4(0, 0, 0, 0);   // 4 KB of zeros
+    for (int i = tid; i < k6PlaneBytes / 16; i += 256) ((uint4*)(lds + k6ZeroOff))[i] = make_uint4(0, 0, 0, 0);   // the zero plane
     __syncthreads();
 
     f32x4 acc[4][k6NT];   // [xi][N-tile]
@@ -203,27 +211,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                 }
     }
 
-    // V addressing.  Tile T = (p*6 + row)*3 + j at T*1024; inside a tile xi*256 + 16 * (slot ^ key) with slot = half*8 + chunk
-    // (chunk = 4 kk + g4 for a reader) and key = 2 * (pr & 7) of the tile's (position, row) index pr.  ds_read_b128 is
-    // served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), which mix two
-    // k-groups; this key keeps the 16 slots of every group distinct for all three row taps (pr - 1, pr, pr + 1) -- found
-    // by exhaustive search over that model.  (The first key, (pr & 7) with the halves swapped by bit 3, was conflict-free
-    // only for the middle tap: 93 B/clk of LDS reads, and the convolution no faster on eight waves than on four.)  For a
-    // fixed lane the k-step kk = 1 is the address XOR 64 and the lo half the address XOR 128; j and xi are immediate offsets.
+    // V addressing (see the header): run (j, xi, k-step, half) of plane (lane group, k-group) at lg * 48 KB + g4 * 12 KB +
+    // k6_run(...), column c at + 16 c.  A reader lane (c, g4) of lane group lg and row tap d takes column lg * 16 + c + d - 1
+    // -- the same position's neighbouring row -- or the zero plane; j, xi, k-step and half are immediate offsets.  A writer
+    // lane holds four consecutive channels (8 bytes of a 16-byte chunk): channels 16 wave + 4 g4 + r = chunk 2 wave + (g4 >> 1)
+    // of the 64, i.e. k-step wave >> 1, k-group 2 (wave & 1) + (g4 >> 1), bytes 8 (g4 & 1) of its column's slot.
     const int ch0 = wave * 16 + 4 * g4;                       // + r: this lane's four output channels
-    const uint32_t wchunk = (uint32_t)(2 * wave + (g4 >> 1)); // 16-byte chunk of those channels (0..7)
-    uint32_t wr_off[3];    // store address of (lane group, j = 0, xi = 0), hi half
-    uint32_t rd_base[3][3];  // read address of (lane group, row tap), k-step 0, hi half, j = 0, xi = 0 -- or the zero block
+    uint32_t wr_off[3];      // store address of (lane group; j = 0, xi = 0, hi half), this wave's k-step
+    uint32_t rd_base[3][3];  // read address of (lane group, row tap): run 0 -- or the zero plane
 #pragma unroll
     for (int lg = 0; lg < 3; ++lg) {
-        const uint32_t pr = (uint32_t)pr_l[lg];
-        wr_off[lg] = pr * 3u * k6TileBytes + ((wchunk << 4) ^ ((pr & 7u) << 5)) + 8u * (uint32_t)(g4 & 1);
+        wr_off[lg] = (uint32_t)(lg * k6LgBytes + (2 * (wave & 1) + (g4 >> 1)) * k6PlaneBytes + k6_run(0, 0, wave >> 1, 0) + c * 16 +
+                                8 * (g4 & 1));
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int rs = row_l[lg] + d - 1;
-            const uint32_t ps = (uint32_t)(pr_l[lg] + d - 1);   // (position, source row): same position when rs is on the board
-            const uint32_t low = (((uint32_t)g4) << 4) ^ ((ps & 7u) << 5);
-            rd_base[lg][d] = (rs >= 0 && rs < k6BS) ? ps * 3u * k6TileBytes + low : (uint32_t)k6ZeroOff + low;
+            const int ps = pr_l[lg] + d - 1;   // (position, source row): same position when rs is on the board
+            rd_base[lg][d] = (rs >= 0 && rs < k6BS) ? (uint32_t)((ps >> 4) * k6LgBytes + g4 * k6PlaneBytes + (ps & 15) * 16)
+                                                    : (uint32_t)(k6ZeroOff + (ps & 15) * 16);   // its own slot: no bank shared
+                                                                                                  // with a live lane of the k-group
         }
     }
 
@@ -280,9 +286,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                     const f32x2 zero2 = {0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        uint32_t wo = wr_off[lg] + j * k6TileBytes;
-                        asm volatile("" : "+v"(wo));   // one base register + immediate offsets
-                        const uint32_t wol = wo ^ 128u;  // the lo half of the same chunk
                         f32x2 V[4][2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                             hi.y = wpack(V[xi][1].x, V[xi][1].y);
                             lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
                             lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
-                            *(uint2*)(lds + wo + xi * 256) = hi;
-                            *(uint2*)(lds + wol + xi * 256) = lo;
+                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 0)) = hi;
+                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 1)) = lo;
                         }
                     }
                 }
@@ -330,9 +333,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         // over a group, the eight weight loads of the next group sit between the MFMAs.  step q = (g*9 + nt)*4 + xi.
         constexpr int GS = k6NT * 4;            // steps of a group
         constexpr int QT = k6Groups * GS;       // steps of a layer
-        auto src_of = [&](int q) -> uint32_t {
+        auto src_of = [&](int q, int half) -> uint32_t {
+#ifdef OTH_W6_ABL_LINEAR   // timing ablation (wrong results): every read a plain lane-linear 1 KB row
+            return (uint32_t)(wave * 32768 + (q & 15) * 2048 + half * 1024 + lane * 16);
+#endif
             const int xi = q & 3, nt = (q >> 2) % k6NT, grp = q / GS, kk = grp & 1, d = grp >> 1;
-            return (rd_base[nt / 3][d] ^ (uint32_t)(kk << 6)) + (uint32_t)((nt % 3) * k6TileBytes + xi * 256);
+            return rd_base[nt / 3][d] + (uint32_t)k6_run(nt % 3, xi, kk, half);
         };
 #ifndef OTH_W6PD
 #define OTH_W6PD 2
@@ -341,9 +347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
-            const uint32_t s = src_of(q);
-            xh[q] = *(const half8*)(lds + s);
-            xl[q] = *(const half8*)(lds + (s ^ 128u));
+            xh[q] = *(const half8*)(lds + src_of(q, 0));
+            xl[q] = *(const half8*)(lds + src_of(q, 1));
         }
         auto conv_d = [&](auto DC) {
             constexpr int D = decltype(DC)::value;
@@ -358,18 +363,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                 if (q < GS) acc[xi][nt] = w6mfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = w6mfma(wh, xl[sl], acc[xi][nt]);
                 OTH_W6SB;
-                if (q + PD < QT) xh[psl] = *(const half8*)(lds + src_of(q + PD));
+#ifndef OTH_W6_ABL_NOLDS   // timing ablations (wrong results by construction): no operand reads / no weight loads
+                if (q + PD < QT) xh[psl] = *(const half8*)(lds + src_of(q + PD, 0));
+#else
+                asm volatile("" : "+v"(xh[psl]));   // opaque: the MFMAs stay
+#endif
                 OTH_W6SB;
                 acc[xi][nt] = w6mfma(wh, xh[sl], acc[xi][nt]);
                 OTH_W6SB;
-                if (q + PD < QT) xl[psl] = *(const half8*)(lds + (src_of(q + PD) ^ 128u));
+#ifndef OTH_W6_ABL_NOLDS
+                if (q + PD < QT) xl[psl] = *(const half8*)(lds + src_of(q + PD, 1));
+#else
+                asm volatile("" : "+v"(xl[psl]));
+#endif
                 if (grp == k6Groups - 2 && step == GS / 2) {
                     b4n = *(const float4*)(a.bias + (layer + 1) * k6F + ch0);
                     invn = a.inv[layer + 1];
                 }
                 // next group's fragments, one per step from the group's first step on (the last group loads group 0 of
                 // the NEXT convolution: the layers are contiguous and one zero group pads the end of the array)
+#ifndef OTH_W6_ABL_NOW
                 if (step < 8) wq[(grp + 1) & 1][step] = wl[(size_t)(grp + 1) * k6GroupU4 + (size_t)step * 64];
+#else
+                if (step < 8) asm volatile("" : "+v"(wq[(grp + 1) & 1][step]));
+#endif
                 OTH_W6SB;
                 acc[xi][nt] = w6mfma(wlo, xh[sl], acc[xi][nt]);
                 OTH_W6SB;
@@ -420,321 +437,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
     OTH_W6STAMP(4)
     if (a.dbg && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int i = 0; i < 5; ++i) o[i] = ph_[i];
-        o[5] = w6_clk() - tstart_;
-        o[6] = w6_realclk() - rstart_;
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_trunk_w6b (experiment, OTH_WINO6=2; correct -- the parity and reproducibility tests pass with it -- but not faster: 0.255
-// vs 0.244 ms per 4096 positions; stamps: convolutions 13.4 k + barriers / exchange 6.1-6.7 k + epilogue 4.3-5.8 k cycles per
-// layer): the same network and arithmetic on EIGHT waves (two per SIMD).  Wave (cb, xp): output channels [16 cb,
-// 16 cb + 16), transformed taps xi = 2 xp and 2 xp + 1 -- 18 accumulators in VGPRs (in-place asm MFMAs again), half the
-// weight fragments and half the operand reads of a four-wave wave, and a partner on its SIMD to fill the issue slots of
-// its ds_read_b128s.  The output transform needs all four taps, so after a convolution every wave publishes its
-// accumulators in the (then dead) V buffer, and takes from its partner's the halves it needs: wave xp finishes channel
-// pair h = xp of the lane's four channels for all nine N-tiles (bias, skip, ReLU, input transform, re-split), i.e. the
-// epilogue's work is split evenly too.  Four barriers per layer instead of two.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 w6bmfma(half8 a, half8 b, f32x4 c) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-    return c;
-}
-__device__ __forceinline__ f32x4 w6bmfma0(half8 a, half8 b) {
-    f32x4 c;
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
-    return c;
-}
-
-__global__ __launch_bounds__(512, 2) void k_trunk_w6b(Wino6Args a, const uint64_t* __restrict__ sb,
-                                                      const uint64_t* __restrict__ ob, const uint64_t* __restrict__ lgl,
-                                                      int64_t n, const int32_t* __restrict__ n_valid,
-                                                      float* __restrict__ logp, float* __restrict__ vout) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    int64_t nv = n;
-    if (n_valid) {
-        const int64_t k = *n_valid;
-        nv = k < n ? k : n;
-    }
-    const int64_t pos0 = (int64_t)blockIdx.x * k6TP;
-    if (pos0 >= nv) return;
-#ifdef OTH_STAMPS
-    unsigned long long ph_[5] = {0, 0, 0, 0, 0}, t0_ = w6_clk();   // prologue + stem | barriers + exchange | epilogues | convolutions | heads
-    const unsigned long long tstart_ = t0_, rstart_ = w6_realclk();
-#endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cb = wave & 3, xp = wave >> 2;   // channel block, tap pair
-    const int g4 = lane >> 4, c = lane & 15;
-
-    // ---- stem input: im2col as in k_trunk_w6 (rows of odd-x output cells negated)
-    for (int ci = tid; ci < k6TP * k6Cells; ci += 512) {
-        const int p = ci / k6Cells, cell = ci % k6Cells, y = cell / k6BS, x = cell % k6BS;
-        const bool live = pos0 + p < nv;
-        const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
-        const _Float16 one = (x & 1) ? (_Float16)(-k6ActScale) : (_Float16)k6ActScale;
-        _Float16 vals[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            const bool ok = yy >= 0 && yy < k6BS && xx >= 0 && xx < k6BS;
-            const int s = ok ? yy * k6BS + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-        }
-        half8* dst = (half8*)(lds + ci * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            half8 t;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = vals[q * 8 + i];
-            dst[q] = t;
-        }
-    }
-    if (tid < 256) ((uint4*)(lds + k6ZeroOff))[tid] = make_uint4(0, 0, 0, 0);   // 4 KB of zeros
-    __syncthreads();
-
-    f32x4 acc[2][k6NT];   // [local tap][N-tile]
-    f32x2 res[k6NT][2];   // [N-tile][x parity]: this wave's channel pair of the residual, fp32, x 2^4
-#pragma unroll
-    for (int xl = 0; xl < 2; ++xl)
-#pragma unroll
-        for (int nt = 0; nt < k6NT; ++nt) {
-            acc[xl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            OTH_PIN_ACC(acc[xl][nt]);
-        }
-    OTH_PIN_ACC_END();
-#pragma unroll
-    for (int nt = 0; nt < k6NT; ++nt) res[nt][0] = res[nt][1] = f32x2{0.f, 0.f};
-
-    int pr_l[3], p_l[3], row_l[3];
-#pragma unroll
-    for (int lg = 0; lg < 3; ++lg) {
-        pr_l[lg] = lg * 16 + c;
-        p_l[lg] = pr_l[lg] / k6BS;
-        row_l[lg] = pr_l[lg] % k6BS;
-    }
-
-    {   // ---- stem conv: wave xp = 0 computes M0 = y0 (even-x cells) into its local tap 0, wave xp = 1 computes M3 = -y1
-        //      (odd-x cells, negated rows) into its local tap 1; the other local tap stays zero (M1 = M2 = 0)
-        const uint4* wp = a.stem + (size_t)cb * 2 * 64 + lane;
-        const half8 wh = __builtin_bit_cast(half8, wp[0]), wlo = __builtin_bit_cast(half8, wp[64]);
-#pragma unroll
-        for (int lg = 0; lg < 3; ++lg)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int cell = p_l[lg] * k6Cells + row_l[lg] * k6BS + 2 * j + xp;
-                const half8 xh = *(const half8*)(lds + cell * 64 + g4 * 16);
-                if (xp == 0) {
-                    acc[0][lg * 3 + j] = w6bmfma(wlo, xh, acc[0][lg * 3 + j]);
-                    acc[0][lg * 3 + j] = w6bmfma(wh, xh, acc[0][lg * 3 + j]);
-                } else {
-                    acc[1][lg * 3 + j] = w6bmfma(wlo, xh, acc[1][lg * 3 + j]);
-                    acc[1][lg * 3 + j] = w6bmfma(wh, xh, acc[1][lg * 3 + j]);
-                }
-            }
-    }
-
-    // V addressing as in k_trunk_w6; this wave's taps are xi = 2 xp + xl: 512 xp is folded into the bases
-    const int ch0 = cb * 16 + 4 * g4 + 2 * xp;                // + r (0, 1): this wave's two output channels of the lane's four
-    const uint32_t wchunk = (uint32_t)(2 * cb + (g4 >> 1));
-    uint32_t wr_off[3];      // store address of (lane group, j = 0, xi = 0), hi half, this wave's channel pair
-    uint32_t rd_base[3][3];  // read address of (lane group, row tap), k-step 0, hi half, j = 0, local tap 0
-#pragma unroll
-    for (int lg = 0; lg < 3; ++lg) {
-        const uint32_t pr = (uint32_t)pr_l[lg];
-        wr_off[lg] = pr * 3u * k6TileBytes + ((wchunk << 4) ^ ((pr & 7u) << 5)) + 8u * (uint32_t)(g4 & 1) +
-                     4u * (uint32_t)xp;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int rs = row_l[lg] + d - 1;
-            const uint32_t ps = (uint32_t)(pr_l[lg] + d - 1);
-            const uint32_t low = (((uint32_t)g4) << 4) ^ ((ps & 7u) << 5);
-            rd_base[lg][d] = ((rs >= 0 && rs < k6BS) ? ps * 3u * k6TileBytes + low : (uint32_t)k6ZeroOff + low) + 512u * (uint32_t)xp;
-        }
-    }
-    // exchange buffer (aliases V while it is dead): accumulator (wave W, local tap xl, N-tile nt) at ((W*18 + xl*9 + nt)*64 + lane)*16
-    const uint32_t x_mine = (uint32_t)((wave * 18) * 64 + lane) * 16u;
-    const uint32_t x_part = (uint32_t)(((wave ^ 4) * 18) * 64 + lane) * 16u + 8u * (uint32_t)xp;   // the partner's, my channel pair
-
-    const int n_layers = 1 + a.n_res_layers;
-    uint32_t sat_bits = 0;
-    OTH_W6STAMP(0)
-    uint4 wq[2][4];   // weight ring: [group parity][local tap hi, lo]
-    float2 b2 = *(const float2*)(a.bias + ch0), b2n = b2;
-    float inv = a.inv[0], invn = inv;
-    for (int layer = 0; layer < n_layers; ++layer) {
-        const bool last = layer == n_layers - 1;
-        if (layer > 0) {
-            b2 = b2n;
-            inv = invn;
-        }
-        const f32x2 inv2 = {inv, inv}, bb = {b2.x, b2.y};
-        // A fragments of conv `layer+1`: group g at wl + g * k6GroupU4; this wave's are fragments 4 xp .. 4 xp + 3 of its block
-        const uint4* wl = a.w + (size_t)layer * (k6Groups * k6GroupU4) + (size_t)cb * (8 * 64) + (size_t)(4 * xp) * 64 + lane;
-        if (layer == 0 && !last) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) wq[0][f] = wl[(size_t)f * 64];
-        }
-        OTH_W6STAMP(3)
-        w6barrier();   // B1: every wave has finished reading V (or the stem's im2col)
-        // publish the accumulators
-#pragma unroll
-        for (int xl = 0; xl < 2; ++xl)
-#pragma unroll
-            for (int nt = 0; nt < k6NT; ++nt) *(f32x4*)(lds + x_mine + (uint32_t)((xl * 9 + nt) * 1024)) = acc[xl][nt];
-        w6barrier();   // B2
-        f32x2 pm[2][k6NT];   // the partner's taps, my channel pair
-#pragma unroll
-        for (int xl = 0; xl < 2; ++xl)
-#pragma unroll
-            for (int nt = 0; nt < k6NT; ++nt) pm[xl][nt] = *(const f32x2*)(lds + x_part + (uint32_t)((xl * 9 + nt) * 1024));
-        w6barrier();   // B3: the exchange buffer is read; V may be written
-        OTH_W6STAMP(1)
-        auto epilogue = [&](auto SKIP) {
-            constexpr bool add_res = decltype(SKIP)::value;
-#pragma unroll
-            for (int lg = 0; lg < 3; ++lg) {
-                f32x2 v0[3], v1[3];   // [tile column j]: outputs x = 2j, 2j+1, this wave's channel pair
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int nt = lg * 3 + j;
-                    const f32x2 o0 = whalf(acc[0][nt], xp), o1 = whalf(acc[1][nt], xp);   // my taps 2 xp, 2 xp + 1
-                    const f32x2 m0 = xp == 0 ? o0 : pm[0][nt], m1 = xp == 0 ? o1 : pm[1][nt];
-                    const f32x2 m2 = xp == 0 ? pm[0][nt] : o0, m3 = xp == 0 ? pm[1][nt] : o1;
-                    const f32x2 t0 = pk_fma(pk_add(pk_add(m0, m1), m2), inv2, bb);
-                    const f32x2 t1 = pk_fma(pk_sub(pk_sub(m1, m2), m3), inv2, bb);
-                    if (add_res) {
-                        pk_add_relu_inplace(res[nt][0], t0, k6Clamp);
-                        pk_add_relu_inplace(res[nt][1], t1, k6Clamp);
-                        v0[j] = res[nt][0];
-                        v1[j] = res[nt][1];
-                    } else {
-                        v0[j] = f32x2{__builtin_amdgcn_fmed3f(t0.x, 0.f, k6Clamp), __builtin_amdgcn_fmed3f(t0.y, 0.f, k6Clamp)};
-                        v1[j] = f32x2{__builtin_amdgcn_fmed3f(t1.x, 0.f, k6Clamp), __builtin_amdgcn_fmed3f(t1.y, 0.f, k6Clamp)};
-                    }
-                    sat_bits = max(sat_bits, max(max(__float_as_uint(v0[j].x), __float_as_uint(v0[j].y)),
-                                                 max(__float_as_uint(v1[j].x), __float_as_uint(v1[j].y))));
-                }
-                if (!last) {
-                    const f32x2 zero2 = {0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        uint32_t wo = wr_off[lg] + j * k6TileBytes;
-                        asm volatile("" : "+v"(wo));
-                        const uint32_t wol = wo ^ 128u;
-                        const f32x2 d0 = j > 0 ? v1[j > 0 ? j - 1 : 0] : zero2, d3 = j < 2 ? v0[j < 2 ? j + 1 : 2] : zero2;
-                        f32x2 V[4];
-                        V[0] = pk_sub(d0, v1[j]);
-                        V[1] = pk_add(v0[j], v1[j]);
-                        V[2] = pk_sub(v1[j], v0[j]);
-                        V[3] = pk_sub(v0[j], d3);
-#pragma unroll
-                        for (int xi = 0; xi < 4; ++xi) {
-                            const uint32_t hi = wpack(V[xi].x, V[xi].y);
-                            const uint32_t lo = wresid(hi, V[xi].x, V[xi].y);
-                            *(uint32_t*)(lds + wo + xi * 256) = hi;
-                            *(uint32_t*)(lds + wol + xi * 256) = lo;
-                        }
-                    }
-                }
-                OTH_W6SB;
-            }
-        };
-        using T_ = std::true_type;
-        using F_ = std::false_type;
-        if (layer & 1) epilogue(F_{});
-        else epilogue(T_{});
-        OTH_W6STAMP(2)
-        if (last) break;
-        w6barrier();   // B4
-        OTH_W6STAMP(1)
-
-        // ---------------- conv `layer+1`: 6 groups x 18 steps (N-tile, local tap) x 3 split products
-        constexpr int GS = k6NT * 2;
-        constexpr int QT = k6Groups * GS;
-        auto src_of = [&](int q) -> uint32_t {
-            const int xl = q & 1, nt = (q >> 1) % k6NT, grp = q / GS, kk = grp & 1, d = grp >> 1;
-            return (rd_base[nt / 3][d] ^ (uint32_t)(kk << 6)) + (uint32_t)((nt % 3) * k6TileBytes + xl * 256);
-        };
-        constexpr int PD = 2;
-        half8 xh[PD + 1], xl_[PD + 1];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            const uint32_t s0 = src_of(q);
-            xh[q] = *(const half8*)(lds + s0);
-            xl_[q] = *(const half8*)(lds + (s0 ^ 128u));
-        }
-        auto conv_d = [&](auto DC) {
-            constexpr int D = decltype(DC)::value;
-#pragma unroll
-            for (int ql = 0; ql < 2 * GS; ++ql) {
-                const int q = D * 2 * GS + ql;
-                const int xl = q & 1, nt = (q >> 1) % k6NT, grp = q / GS, sl = q % (PD + 1), psl = (q + PD) % (PD + 1);
-                const int step = q % GS;
-#ifdef OTH_W6B_NTLO   // timing ablation only (wrong results): N-tiles [OTH_W6B_NTLO, OTH_W6B_NTHI) only
-                if (nt < OTH_W6B_NTLO || nt >= OTH_W6B_NTHI) continue;
-#endif
-                const half8 wh = __builtin_bit_cast(half8, wq[grp & 1][2 * xl]);
-                const half8 wlo = __builtin_bit_cast(half8, wq[grp & 1][2 * xl + 1]);
-                OTH_W6SB;
-                if (q < GS) acc[xl][nt] = w6bmfma0(wh, xl_[sl]);
-                else acc[xl][nt] = w6bmfma(wh, xl_[sl], acc[xl][nt]);
-                OTH_W6SB;
-                if (q + PD < QT) xh[psl] = *(const half8*)(lds + src_of(q + PD));
-                OTH_W6SB;
-                acc[xl][nt] = w6bmfma(wh, xh[sl], acc[xl][nt]);
-                OTH_W6SB;
-                if (q + PD < QT) xl_[psl] = *(const half8*)(lds + (src_of(q + PD) ^ 128u));
-                if (grp == k6Groups - 2 && step == GS / 2) {
-                    b2n = *(const float2*)(a.bias + (layer + 1) * k6F + ch0);
-                    invn = a.inv[layer + 1];
-                }
-                if (step < 4) wq[(grp + 1) & 1][step] = wl[(size_t)(grp + 1) * k6GroupU4 + (size_t)step * 64];
-                OTH_W6SB;
-                acc[xl][nt] = w6bmfma(wlo, xh[sl], acc[xl][nt]);
-                OTH_W6SB;
-            }
-        };
-        conv_d(std::integral_constant<int, 0>{});
-        conv_d(std::integral_constant<int, 1>{});
-        conv_d(std::integral_constant<int, 2>{});
-    }
-
-    // ---------------- heads: final activations (in `res`, this wave's channel pair) -> LDS planes, then ONE position per wave
-    if (sat_bits >= __float_as_uint(k6Clamp)) atomicOr(a.sat, 1);
-    __syncthreads();
-    constexpr int NCO = k6TP * k6Cells;   // 288
-    float* planes = (float*)lds;
-#pragma unroll
-    for (int lg = 0; lg < 3; ++lg)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int ci = p_l[lg] * k6Cells + row_l[lg] * k6BS + 2 * j + e;
-                const f32x2 v = res[lg * 3 + j][e];
-                planes[(ch0 + 0) * NCO + ci] = v.x * (1.0f / k6ActScale);
-                planes[(ch0 + 1) * NCO + ci] = v.y * (1.0f / k6ActScale);
-            }
-    __syncthreads();
-    {
-        float* scratch = (float*)(lds + (size_t)k6F * NCO * 4) + wave * 192;
-        const int cc = lane < k6Cells ? lane : 0;
-        const float* srcs[1] = {planes + wave * k6Cells + cc};
-        float* lps[1] = {logp + (pos0 + wave) * k6NP};
-        float* vs[1] = {vout + pos0 + wave};
-        const bool live[1] = {pos0 + wave < nv};
-        heads_wave_n<k6F, k6BS, 1>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
-    }
-#ifdef OTH_STAMPS
-    OTH_W6STAMP(4)
-    if (a.dbg && lane == 0) {
-        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
         for (int i = 0; i < 5; ++i) o[i] = ph_[i];
         o[5] = w6_clk() - tstart_;
         o[6] = w6_realclk() - rstart_;
@@ -871,40 +573,6 @@ int wino6_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const ui
         attr_set = true;
     }
     const unsigned grid = (unsigned)((n + k6TP - 1) / k6TP);
-    {
-        const char* e = getenv("OTH_WINO6");   // read per call: the variants test toggles it
-        if (e && atoi(e) == 2) {   // the eight-wave build (experiment switch)
-            static bool attr_b[64] = {};
-            if (!attr_b[net->device & 63]) {
-                OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_w6b, hipFuncAttributeMaxDynamicSharedMemorySize, k6Lds));
-                attr_b[net->device & 63] = true;
-            }
-#ifdef OTH_STAMPS
-            OTH_HIP(hipMalloc(&a.dbg, (size_t)grid * 8 * 8 * sizeof(unsigned long long)));
-            OTH_HIP(hipMemset(a.dbg, 0, (size_t)grid * 8 * 8 * sizeof(unsigned long long)));
-#endif
-            hipLaunchKernelGGL(k_trunk_w6b, dim3(grid), dim3(512), k6Lds, stream, a, sb, ob, lg, n, n_valid, logp, v);
-            OTH_HIP(hipGetLastError());
-#ifdef OTH_STAMPS
-            OTH_HIP(hipStreamSynchronize(stream));
-            {
-                std::vector<unsigned long long> h((size_t)grid * 8 * 8);
-                OTH_HIP(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
-                double sm[7] = {0, 0, 0, 0, 0, 0, 0};
-                size_t nw = 0;
-                for (size_t w = 0; w < (size_t)grid * 8; ++w) {
-                    if (!h[w * 8 + 5]) continue;
-                    ++nw;
-                    for (int i = 0; i < 7; ++i) sm[i] += (double)h[w * 8 + i];
-                }
-                fprintf(stderr, "[w6b stamps] per-wave cycles: prologue+stem %.0f | barriers + exchange %.0f | epilogues %.0f | convolutions %.0f | heads %.0f | total %.0f | clock %.3f GHz\n",
-                        sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw, sm[5] / nw, sm[5] / sm[6] * 0.1);
-                (void)hipFree(a.dbg);
-            }
-#endif
-            return OTH_OK;
-        }
-    }
 #ifdef OTH_STAMPS
     OTH_HIP(hipMalloc(&a.dbg, (size_t)grid * 4 * 8 * sizeof(unsigned long long)));
     OTH_HIP(hipMemset(a.dbg, 0, (size_t)grid * 4 * 8 * sizeof(unsigned long long)));
