@@ -33,6 +33,7 @@ namespace oth {
 
 using half8 = _Float16 __attribute__((ext_vector_type(8)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));   // a weight fragment as a register operand (HIP's uint4 is a struct)
 
 constexpr int k6F = 64, k6BS = 6, k6Cells = 36, k6NP = 37, k6TP = 8;
 constexpr int k6NT = 9;                         // N-tiles of a wave: 3 lane groups x 3 tile columns
@@ -92,21 +93,37 @@ __device__ __forceinline__ unsigned long long w6_realclk() {
 #define OTH_W6STAMP(i)
 #endif
 
-// The builtin, not the in-place inline asm of net_wino.hip: 36 accumulators + 18 residual registers + the weight ring need
-// more than 256 architectural VGPRs, and with asm MFMAs hipcc parked WEIGHT fragments in AGPRs and copied them back right
-// in front of their MFMA (no wait states: tools/check_mfma_hazards.py flagged every one).  With the builtin the allocator
-// may keep the accumulators themselves in AGPRs (MFMA reads and writes them there) and knows the hazards.
-// In-kernel stamps (-DOTH_STAMPS) of this build, per wave and layer: convolution 18.8 k cycles for 648 MFMAs (29 cycles per
-// MFMA; 17.8 k with the conflict-free key below), epilogue 6.6 k.  Timing ablations with fewer N-tiles and VGPR accumulators: 21.6 cycles per MFMA -- with one wave
-// per SIMD the two ds_read_b128 of a step cost their ~8 issue cycles each on top of its three MFMAs (48 + 16), and AGPR
-// accumulators add ~7 cycles per MFMA.  Not cured by a longer LDS look-ahead (3 / 4 / 6 steps), by interleaving the MFMAs
-// of two steps, or by asm MFMAs with the residual pinned into AGPRs (the allocator then migrates accumulators right after
-// their MFMA: 64 hazards), nor by eight waves (k_trunk_w6b below: the SIMD's 648 MFMAs still take ~19 k cycles).  Open.
-__device__ __forceinline__ f32x4 w6mfma(half8 a, half8 b, f32x4 c) {
+// MFMA forms.  The builtin (default): 36 accumulators + 18 residual registers + the weight ring need more than 256
+// architectural VGPRs; with the builtin the allocator keeps the accumulators in AGPRs (MFMA reads and writes them there) and
+// knows the hazards.  -DOTH_W6_ASM=1 (round-4 experiment, kept buildable): in-place asm MFMAs whose A operand -- the weight
+// fragment -- is an AGPR operand ("a": an MFMA reads A / B from either file), so that the weight ring (loaded from L2
+// straight into AGPRs: `global_load_dwordx4 a[..]`) and the residual live in the AGPR half and the 36 accumulators in VGPRs --
+// worth 2 cycles per MFMA for a lone wave in isolation (tools/probes/probe_w6_step.hip: 16.7 vs 18.7).  In the kernel:
+// convolution 120.4 k vs 122.7 k cycles, but hipcc parks all 36 accumulators in AGPRs around the epilogue anyway (288 copies
+// per layer instead of the builtin's 144 reads), so the launch is no faster (0.222 vs 0.222 ms, interleaved A/B) -- and the
+// form is fragile: the same source under the stamps build's register pressure gets accumulator copies right behind the asm
+// MFMAs (102 hazards by tools/check_mfma_hazards.py, and indeed wrong outputs: 2.4e-2).  Not shipped.
+#ifndef OTH_W6_ASM
+#define OTH_W6_ASM 0
+#endif
+__device__ __forceinline__ f32x4 w6mfma(u32x4 a4, half8 b, f32x4 c) {
+    const half8 a = __builtin_bit_cast(half8, a4);
+#if OTH_W6_ASM
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
-__device__ __forceinline__ f32x4 w6mfma0(half8 a, half8 b) {   // first product of a chain: C = 0
+__device__ __forceinline__ f32x4 w6mfma0(u32x4 a4, half8 b) {   // first product of a chain: C = 0
+    const half8 a = __builtin_bit_cast(half8, a4);
+#if OTH_W6_ASM
+    f32x4 c;
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "a"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ void w6barrier() {   // LDS-only barrier: global weight prefetches stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -206,8 +223,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                 for (int e = 0; e < 2; ++e) {
                     const int cell = p_l[lg] * k6Cells + row_l[lg] * k6BS + 2 * j + e;
                     const half8 xh = *(const half8*)(lds + cell * 64 + g4 * 16);
-                    acc[3 * e][lg * 3 + j] = w6mfma(wlo, xh, acc[3 * e][lg * 3 + j]);
-                    acc[3 * e][lg * 3 + j] = w6mfma(wh, xh, acc[3 * e][lg * 3 + j]);
+                    acc[3 * e][lg * 3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, acc[3 * e][lg * 3 + j], 0, 0, 0);
+                    acc[3 * e][lg * 3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[3 * e][lg * 3 + j], 0, 0, 0);
                 }
     }
 
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
     OTH_W6STAMP(0)
-    uint4 wq[2][8];   // weight ring: [group parity][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments
+    u32x4 wq[2][8];   // weight ring: [group parity][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments
     float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x 2^4) and 1 / weight scale of the layer in the epilogue
     float inv = a.inv[0], invn = inv;
     for (int layer = 0; layer < n_layers; ++layer) {
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         }
         const f32x2 inv2 = {inv, inv};
         // A fragments of conv `layer+1`: group g at wl + g * k6GroupU4
-        const uint4* wl = a.w + (size_t)layer * (k6Groups * k6GroupU4) + (size_t)wave * (8 * 64) + lane;
+        const u32x4* wl = (const u32x4*)a.w + (size_t)layer * (k6Groups * k6GroupU4) + (size_t)wave * (8 * 64) + lane;
         // ---------------- epilogue of conv `layer`: output transform, scale, bias, skip, ReLU; then the next layer's
         //                  input transform and the hi/lo re-split into V.  Two variants (net_wino.hip): SKIP for the stem
         //                  (zero residual) and the second convolution of a block, plain for the first.
@@ -345,6 +362,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
 #endif
         constexpr int PD = OTH_W6PD;   // LDS operand pairs in flight ahead of the MFMAs (steps)
         half8 xh[PD + 1], xl[PD + 1];
+#if OTH_W6_ASM
+        // The first group's fragments are loop-carried (loaded in the previous layer's last group, or above for layer 0):
+        // hipcc reconciles their registers with v_accvgpr_mov copies which it sinks right in front of the first MFMAs --
+        // invisible hazards for asm MFMAs (tools/check_mfma_hazards.py flagged 14).  Pinned here, in the AGPR class, in
+        // front of the two wait states a VALU write needs before an MFMA reads it.
+#pragma unroll
+        for (int f = 0; f < 8; ++f) asm volatile("" : "+a"(wq[0][f]));
+        asm volatile("s_nop 1" ::: "memory");
+        OTH_W6SB;
+#endif
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
             xh[q] = *(const half8*)(lds + src_of(q, 0));
@@ -357,8 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                 const int q = D * 2 * GS + ql;
                 const int xi = q & 3, nt = (q >> 2) % k6NT, grp = q / GS, sl = q % (PD + 1), psl = (q + PD) % (PD + 1);
                 const int step = q % GS;
-                const half8 wh = __builtin_bit_cast(half8, wq[grp & 1][2 * xi]);
-                const half8 wlo = __builtin_bit_cast(half8, wq[grp & 1][2 * xi + 1]);
+                const u32x4 wh = wq[grp & 1][2 * xi], wlo = wq[grp & 1][2 * xi + 1];
                 OTH_W6SB;
                 if (q < GS) acc[xi][nt] = w6mfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = w6mfma(wh, xl[sl], acc[xi][nt]);
@@ -395,6 +421,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         conv_d(std::integral_constant<int, 0>{});
         conv_d(std::integral_constant<int, 1>{});
         conv_d(std::integral_constant<int, 2>{});
+#if OTH_W6_ASM
+        // the last asm MFMA's result needs 8 wait states before anything but an MFMA touches it, and hipcc -- which cannot
+        // see that -- may move accumulators right behind the loop's last instruction (the checker found one 6 states behind)
+        asm volatile("s_nop 3" ::: "memory");
+        OTH_W6SB;
+#endif
     }
 
     // ---------------- heads (fp32 VALU): final activations (in `res`, x 2^4) -> LDS planes [channel][8 x 36 cells] f32

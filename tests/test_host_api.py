@@ -256,16 +256,27 @@ def test_hazard_checker_sees_across_branch_edges():
                    ("s_endpgm", "")])
     n, bad, edges, _ = mod.check_text(fwd_bad)
     assert edges == 1 and len(bad) == 1 and "touches the result" in bad[0]
-    fwd_ok = asm([mfma, ("s_nop", "7"), ("s_nop", "2"), ("s_branch", "out"), ("s_nop", "0"), ("L", "out"),
+    fwd_ok = asm([mfma, ("s_nop", "6"), ("s_branch", "out"), ("s_nop", "0"), ("L", "out"),
                   ("v_mov_b32_e32", "v30, v1"), ("s_endpgm", "")])
     assert mod.check_text(fwd_ok)[1] == []
-    # (3) three other MFMAs in between = 12 states: the pipe takes one MFMA per 4 passes
+    # (3) two other MFMAs in between = 8 states (the pipe takes one MFMA per 4 passes): enough for the 4-pass 16x16x32,
+    #     not for an 8-pass 32x32x16 result (12)
     other = ("v_mfma_f32_16x16x32_f16", "v[4:7], v[8:11], v[12:15], v[4:7]")
-    assert mod.check_text(asm([mfma, other, other, other, ("v_mov_b32_e32", "v30, v1")]))[1] == []
-    assert len(mod.check_text(asm([mfma, other, other, ("v_mov_b32_e32", "v30, v1")]))[1]) == 1
+    assert mod.check_text(asm([mfma, other, other, ("v_mov_b32_e32", "v30, v1")]))[1] == []
+    assert len(mod.check_text(asm([mfma, other, ("v_mov_b32_e32", "v30, v1")]))[1]) == 1
+    big = ("v_mfma_f32_32x32x16_f16", "v[0:15], v[16:19], v[20:23], v[0:15]")
+    assert len(mod.check_text(asm([big, other, other, ("v_mov_b32_e32", "v30, v1")]))[1]) == 1
+    assert mod.check_text(asm([big, other, other, other, ("v_mov_b32_e32", "v30, v1")]))[1] == []
     assert mod.find_objdump()
     # (4) rule 3: a packed-fp32 op taking a source's HIGH dword for its low lane (the round-3 value-head defect)
     pk = lambda sel: asm([("v_pk_fma_f32", "v[4:5], v[22:23], v[14:15], v[4:5] " + sel)])   # noqa: E731
     assert len(mod.check_text(pk("op_sel:[0,1,0]"))[1]) == 1
     assert mod.check_text(pk("op_sel_hi:[1,0,1]"))[1] == [] and mod.check_text(pk(""))[1] == []
     assert mod.check_text(asm([("v_pk_fma_f16", "v4, v22, v14, v4 op_sel:[0,1,0]")]))[1] == []   # 16-bit packed ops: not meant
+    # (5) AGPR operands: v_accvgpr_write of an MFMA's A operand right in front of it; an AGPR result read too early
+    amf = ("v_mfma_f32_16x16x32_f16", "v[0:3], a[16:19], v[12:15], v[0:3]")
+    assert len(mod.check_text(asm([("v_accvgpr_write_b32", "a17, v40"), amf]))[1]) == 1
+    assert mod.check_text(asm([("v_accvgpr_write_b32", "a17, v40"), ("s_nop", "1"), amf]))[1] == []
+    assert mod.check_text(asm([("v_accvgpr_write_b32", "a21, v40"), amf]))[1] == []           # another register
+    agm = ("v_mfma_f32_16x16x32_f16", "a[0:3], v[8:11], v[12:15], a[0:3]")
+    assert len(mod.check_text(asm([agm, ("v_accvgpr_read_b32", "v9, a2")]))[1]) == 1

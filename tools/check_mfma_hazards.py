@@ -6,7 +6,8 @@ errors in a 32-filter build of k_trunk_h3 before it was pinned), nor between an 
 
 Disassembles the gfx950 code object of every given .o (llvm-objdump) and fails if
   (1) a VALU instruction writes a source register of a v_mfma within the two preceding wait states, or
-  (2) a non-MFMA instruction touches the result of an MFMA issued fewer than 12 wait states earlier (the 8-pass bound),
+  (2) a non-MFMA instruction touches the result of an MFMA issued fewer than passes + 4 wait states earlier (8 for the
+      4-pass 16x16x32 f16, 12 for the 8-pass shapes),
   (3) any packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) selects the HIGH dword
       of a source pair for its LOW lane (`op_sel:[..1..]`): on gfx950 that operand form returns wrong results now and then
       when two waves share a SIMD (round 4: tools/probes/probe_pk_opsel.hip, heads_batch4_variants.sh -- the cause of the
@@ -27,11 +28,21 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-WINDOW = 14
+# VGPRs v7 / v[4:7] and AGPRs a7 / a[4:7] (numbered 1000 + n: one unified file per lane, two name spaces): an MFMA may take
+# A / B / C from either, and v_accvgpr_write is a VALU write like any other
+REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+WINDOW = 24
 # XDL write of a VGPR -> VALU / LDS / VMEM read or overwrite of it: passes + 3 (+1 on gfx950) wait states, i.e. 12 for an
-# 8-pass MFMA (cdna_hip_programming.md, inline-asm rules: "8-pass XDL: 12 states"), 8 for the 4-pass 16x16x32 f16
-RESULT_WAIT = 12
+# 8-pass MFMA (cdna_hip_programming.md, inline-asm rules: "8-pass XDL: 12 states"), 8 for a 4-pass one.  Passes = pipe
+# cycles / 4 (MI355X_MICROARCH.md cycle constants): 16x16x32 f16 / bf16 = 16 cycles = 4 passes -- hipcc's own hazard
+# recogniser agrees: it places the first read of a builtin 16x16x32 result exactly 8 states behind it -- 32x32x16 and the
+# fp32-input 16x16x4 = 32 cycles = 8 passes; anything else is taken as 16 passes.
+def result_wait(mn):
+    if re.search(r"_16x16x(32|16)_?(f16|bf16|bf8|fp8)", mn) or re.search(r"_16x16x(32|16)(f16|bf16)", mn):
+        return 4 + 4
+    if re.search(r"_32x32x16_?(f16|bf16)|_16x16x4_?f32|_32x32x8", mn):
+        return 8 + 4
+    return 16 + 4
 
 
 def find_objdump():
@@ -56,9 +67,10 @@ def regs(tok):
     out = set()
     for m in REG.finditer(tok):
         if m.group(1) is not None:
-            out.add(int(m.group(1)))
+            out.add(int(m.group(2)) + (1000 if m.group(1) == "a" else 0))
         else:
-            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+            base = 1000 if m.group(3) == "a" else 0
+            out.update(range(base + int(m.group(4)), base + int(m.group(5)) + 1))
     return out
 
 
@@ -146,10 +158,10 @@ def hazards(seq, first_consumer, last_producer):
                 touched |= regs(o)
             dist = 0
             for j in range(i - 1, lo - 1, -1):
-                if dist >= RESULT_WAIT:
+                if dist >= 20:
                     break
                 p = seq[j]
-                if (last_producer is None or j <= last_producer) and p.is_mfma and p.dst & touched:
+                if (last_producer is None or j <= last_producer) and p.is_mfma and dist < result_wait(p.mn) and p.dst & touched:
                     bad.append("%s: `%s` touches the result of `%s` only %d wait state(s) later (0x%x -> 0x%x)"
                                % (c.func, c.text(), p.text(), dist, p.addr, c.addr))
                 dist += p.ws
