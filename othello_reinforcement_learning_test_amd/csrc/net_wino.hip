@@ -211,8 +211,8 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
 // low-latency build for launches of <= 256 positions (every workgroup has a CU to itself there): eight waves still
 // split the 128 channels, so a position's layer is 288 MFMAs per wave instead of the direct kernel's 792 on four.
 // Both builds sum every accumulator in the same order: a position's outputs do not depend on the launch size.
-template <int TP>
-__global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* __restrict__ sb,
+template <int TP, bool PERSIST = false>
+__global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, const uint64_t* __restrict__ sb,
                                                     const uint64_t* __restrict__ ob, const uint64_t* __restrict__ lgl,
                                                     int64_t n, const int32_t* __restrict__ n_valid,
                                                     float* __restrict__ logp, float* __restrict__ vout) {
@@ -226,9 +226,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         nv = k < n ? k : n;
     }
     constexpr int NT = 2 * TP;   // N-tiles of a wave: (position, board half)
-    const int64_t pos0 = (int64_t)blockIdx.x * TP;
-    if (pos0 >= nv) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // A workgroup takes position group blockIdx.x.  PERSIST (OTH_WINO_PERSIST=g, round-4 experiment on the memory-side
+    // traffic): g workgroups loop over every g-th group, so that the weights pass each XCD's L2 once per launch instead of once
+    // per wave of workgroups.  A separate instantiation: the loop around the body costs the default build 324 spilled VGPRs.
+    for (int64_t blk = blockIdx.x; blk * TP < nv; blk += gridDim.x) {
+    const int64_t pos0 = blk * TP;
+    int tid_ = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_));   // opaque per trip: nothing derived from it is hoisted out of the loop
+                                                             // (hoisted, the lane constants cost 324 spilled VGPRs)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c = lane & 15;
     const int row4 = c >> 2, j = c & 3;        // row within the board half, tile column
     // N-tile nt = 2*p + h: position p, board half h; this lane's tile index within the position: 16*h + c
@@ -573,6 +579,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
                  logp + pos0 * 65, vout + pos0);
 #endif
+    if constexpr (!PERSIST) return;   // one trip: no loop in the default build
+    __syncthreads();   // the heads are done with the LDS planes before the next group's stem input overwrites them
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -713,7 +722,15 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     const char* tpe = getenv("OTH_WINO_TP");
     const int tp = tpe ? (atoi(tpe) == 1 ? 1 : 2) : (n <= 256 ? 1 : 2);
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
-    if (tp == 1) hipLaunchKernelGGL(k_trunk_w<1>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    static const int persist = getenv("OTH_WINO_PERSIST") ? atoi(getenv("OTH_WINO_PERSIST")) : 0;
+    if (persist > 0 && tp == 2 && grid > (unsigned)persist) {   // experiment: `persist` looping workgroups
+        static bool pattr[64] = {};
+        if (!pattr[net->device & 63]) {
+            OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_w<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWLds));
+            pattr[net->device & 63] = true;
+        }
+        hipLaunchKernelGGL((k_trunk_w<2, true>), dim3((unsigned)persist), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    } else if (tp == 1) hipLaunchKernelGGL(k_trunk_w<1>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
     else hipLaunchKernelGGL(k_trunk_w<2>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
     OTH_HIP(hipGetLastError());
 #ifdef OTH_STAMPS
