@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
             vs[k] = vout + pos0 + p;
             live[k] = pos0 + p < nv;
         }
-        heads_wave_n<k6F, k6BS, 2>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
+        heads_wave_n<k6F, k6BS, 2, true>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
     }
 #ifdef OTH_STAMPS
     OTH_W6STAMP(4)

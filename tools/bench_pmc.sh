@@ -1,11 +1,11 @@
 #!/bin/bash
 # HBM-side traffic of bench.py's OWN launches (two lanes, ~2 000 positions per trunk launch): separate rocprofv3 --pmc passes
-# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/r03_bench_traffic.json
+# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/r04_bench_traffic.json
 # (copy it to profiles/: bench.py reads roofline.traffic and roofline_rollout.traffic from there) and a text summary.
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-CMD="python3 bench.py --gpus 1 --steps 1 --warmup 2 --step-games 512 --stagger 8 --profile-steps 1 --no-cpu-baseline"
+CMD="python3 bench.py --gpus 1 --steps 1 --warmup 2 --step-games 512 --stagger 8 --profile-steps 1 --no-cpu-baseline --no-other-configs"
 out=gpurun_out/pmc_bench
 rm -rf "$out"; mkdir -p "$out"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
@@ -46,7 +46,7 @@ for kern, v in vals.items():
     }
     if wide:
         res["kernels"][key]["positions_per_launch"] = ppl
-json.dump(res, open("gpurun_out/r03_bench_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r04_bench_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf "$out"/fetch "$out"/write "$out"/tcc

@@ -10,3 +10,12 @@ for path in sys.argv[1:]:
             print("%-48s %-8s %10.1f %s | frac %.3f of %.0f | launch %.3f ms | trunk share %s | tree %.0f ms"
                   % (d["metric"], d["dtype"].split(" ")[0], d["value"], d["unit"], r["frac"], r["peak"], r["avg_launch_ms"],
                      r["net_time_share"], r["tree_kernels_ms"]))
+            for o in d.get("other_configs") or []:
+                if "value" in o:
+                    print("    other_configs %-26s %10.1f %s | frac %.3f | %s | %s" % (
+                        o["config"], o["value"], o["unit"], o["roofline_frac"], o["kernel"].split(" ")[0],
+                        ("cache hit rate %.3f" % o["eval_cache"]["hit_rate"]) if "eval_cache" in o else ""))
+                else:
+                    print("    other_configs", o)
+            if d.get("cpu_baseline"):
+                print("    cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "streams", "kind")})
