@@ -24,6 +24,11 @@ The timed steps run with the engine's HIP-event hooks OFF.  After the timed regi
                streams), against the dense fp16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline the CPU oracle (a C port of the reference algorithm, oracle/) timed on the host cores over a
                bounded, phase-uniform sample of the same workload.  Reported, not targeted.
+  other_configs (N = 1, default workload only; --no-other-configs skips them) three short legs after the headline, same
+               process, same streaming schedule: BASELINE configs[3] (400 sims/move, c_puct 1.5, threshold 20), configs[4]
+               (6x6, 25 sims, 5x64 net; rules parity unpinned) and configs[1] with the opt-in evaluation cache -- secondary
+               figures; `value`, `config` and `roofline` are the headline's alone.
+The roofline object's kernel name and issued-FLOP factor come from the library (oth_net_kernel_info), not from this file.
 """
 import argparse
 import ctypes as C
