@@ -106,6 +106,11 @@ __device__ __forceinline__ unsigned long long w6_realclk() {
 #ifndef OTH_W6_ASM
 #define OTH_W6_ASM 0
 #endif
+#ifndef OTH_W6_ST128
+#define OTH_W6_ST128 0   // 1: 16-byte V stores through v_permlane16_swap (round-4 experiment: conflict-free, and slower -- epilogues
+                         // 47.8 k -> 63.3 k cycles, 0.214 -> 0.222 ms interleaved: a ds_write_b128 moves five source dwords to the LDS
+                         // at 13 cycles against 2 x 6 for the 8-byte pair, plus eight swaps per tile column)
+#endif
 __device__ __forceinline__ f32x4 w6mfma(u32x4 a4, half8 b, f32x4 c) {
     const half8 a = __builtin_bit_cast(half8, a4);
 #if OTH_W6_ASM
@@ -238,8 +243,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
     uint32_t rd_base[3][3];  // read address of (lane group, row tap): run 0 -- or the zero plane
 #pragma unroll
     for (int lg = 0; lg < 3; ++lg) {
+#if OTH_W6_ST128   // the whole slot; odd rows (g4 & 1) store xi + 2 (see the epilogue)
+        wr_off[lg] = (uint32_t)(lg * k6LgBytes + (2 * (wave & 1) + (g4 >> 1)) * k6PlaneBytes + k6_run(0, 0, wave >> 1, 0) + c * 16 +
+                                (g4 & 1) * (k6_run(0, 2, 0, 0) - k6_run(0, 0, 0, 0)));
+#else
         wr_off[lg] = (uint32_t)(lg * k6LgBytes + (2 * (wave & 1) + (g4 >> 1)) * k6PlaneBytes + k6_run(0, 0, wave >> 1, 0) + c * 16 +
                                 8 * (g4 & 1));
+#endif
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int rs = row_l[lg] + d - 1;
@@ -313,16 +323,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                             V[2][h] = pk_sub(v1[j][h], v0[j][h]);
                             V[3][h] = pk_sub(v0[j][h], d3);
                         }
+                        uint2 hi[4], lo[4];
 #pragma unroll
                         for (int xi = 0; xi < 4; ++xi) {
-                            uint2 hi, lo;
-                            hi.x = wpack(V[xi][0].x, V[xi][0].y);
-                            hi.y = wpack(V[xi][1].x, V[xi][1].y);
-                            lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
-                            lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
-                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 0)) = hi;
-                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 1)) = lo;
+                            hi[xi].x = wpack(V[xi][0].x, V[xi][0].y);
+                            hi[xi].y = wpack(V[xi][1].x, V[xi][1].y);
+                            lo[xi].x = wresid(hi[xi].x, V[xi][0].x, V[xi][0].y);
+                            lo[xi].y = wresid(hi[xi].y, V[xi][1].x, V[xi][1].y);
                         }
+#if OTH_W6_ST128
+                        // 16-byte stores: a lane holds 4 of the 8 channels of its column's slot, its partner 16 lanes away
+                        // (g4 ^ 1) the other 4.  v_permlane16_swap trades the xi = a words of the odd row against the xi = a + 2
+                        // words of the even row, so that the even lane ends up with all 8 channels of xi = a and the odd lane with
+                        // all 8 of xi = a + 2: one conflict-free ds_write_b128 each instead of two 2-way-conflicting ds_write_b64.
+#pragma unroll
+                        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const uint2 A = half ? lo[a2] : hi[a2], B = half ? lo[a2 + 2] : hi[a2 + 2];
+                                const auto s0 = __builtin_amdgcn_permlane16_swap(A.x, B.x, false, false);
+                                const auto s1 = __builtin_amdgcn_permlane16_swap(A.y, B.y, false, false);
+                                *(uint4*)(lds + wr_off[lg] + k6_run(j, a2, 0, half)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            }
+#else
+#pragma unroll
+                        for (int xi = 0; xi < 4; ++xi) {
+                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 0)) = hi[xi];
+                            *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 1)) = lo[xi];
+                        }
+#endif
                     }
                 }
                 OTH_W6SB;   // one lane group at a time (without it: no change)
