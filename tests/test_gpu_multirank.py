@@ -68,3 +68,28 @@ def test_distributed_worker_and_exchange_on_rccl_one_rank(children):
     assert d["ok"] is True and d["backend"] == "nccl" and d["world"] == 1 and d["exchange_steps"] == 6
     calls = d["worker_calls"]
     assert len(calls) == 3 and calls[1] < calls[0]      # the second call's tuple count shrank
+
+
+def test_bench_other_configs_leg_small():
+    """bench.py's secondary legs (`other_configs`: BASELINE configs[3], configs[4], configs[1] + evaluation cache) run only
+    behind the full-size headline, so their code path is exercised here at toy size: run_leg on a 6x6 2x32 network (three
+    lanes, as the configs[4] leg) and on an 8x8 2x16 network with the evaluation cache -- keys, kernel names from the library,
+    positive rates, cache hits counted."""
+    import importlib.util
+    import os
+
+    import torch
+
+    import othello_reinforcement_learning_test_amd as pkg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.run_leg(pkg, torch, "toy 6x6", "three lanes", board=6, blocks=2, filters=32, sims=4, games=96, step_games=48,
+                      warmup=1, steps=2, lanes=3, stagger=8)
+    assert a["value"] > 0 and a["games_timed"] >= 96 and a["kernel"].startswith("k_trunk_h3") and a["lanes"] == 3
+    assert 0 < a["roofline_frac"] < 1 and a["mfma_flops_issued_per_algorithmic_flop"] >= 3.0 and a["plies_per_game"] > 20
+    b = bench.run_leg(pkg, torch, "toy cache", "cache on", board=8, blocks=2, filters=16, sims=6, games=64, step_games=32,
+                      warmup=1, steps=2, eval_cache=12, c_puct=1.5, temp_threshold=20, stagger=8)
+    assert b["value"] > 0 and b["kernel"].startswith("k_trunk_f32") and b["eval_cache"]["hits"] > 0
+    assert 0 < b["eval_cache"]["hit_rate"] < 1 and "c_puct 1.50" in b["workload"] and "threshold 20" in b["workload"]
