@@ -25,7 +25,7 @@ __device__ __forceinline__ unsigned long long clk() {
 // READS: ds_read_b128 per step (0, 1, 2); ASM: 0 = builtin MFMA (hipcc keeps the accumulators in VGPRs here), 1 = in-place asm
 // MFMAs on VGPR accumulators, 2 = in-place asm MFMAs on AGPR accumulators; ILV: two accumulators interleaved;
 // B64: each operand as two ds_read_b64; NACC accumulators in the ring
-template <int READS, int ASM, bool ILV, bool B64, int NACC, int PAT = 0, int WOFF = 1280, int SSTR = 8192, int SMOD = 3, int LOOFF = 1024>
+template <int READS, int ASM, bool ILV, bool B64, int NACC, int PAT = 0, int WOFF = 1280, int SSTR = 8192, int SMOD = 3, int LOOFF = 1024, int RB = 1>
 __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int steps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,11 +34,19 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
     half8 wh, wl;
     for (int i = 0; i < 8; ++i) { wh[i] = (_Float16)(0.01f * (lane & 7)); wl[i] = (_Float16)(0.001f * i); }
     f4 acc[NACC];
+    f4 acc2[RB == 2 ? NACC : 1];   // RB = 2: a second row block per step (a 32-channel wave: each operand pair feeds six MFMAs)
+    half8 wh2 = wh, wl2 = wl;
+    if (RB == 2) for (int i = 0; i < 8; ++i) { wh2[i] = (_Float16)(0.02f * (lane & 3)); wl2[i] = (_Float16)(0.003f * i); }
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
         acc[i] = f4{0.f, 0.f, 0.f, 0.f};
         if (ASM == 2) asm volatile("" : "+a"(acc[i]));
         else asm volatile("" : "+v"(acc[i]));
+        if (RB == 2) {
+            acc2[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (ASM == 2) asm volatile("" : "+a"(acc2[i]));
+            else asm volatile("" : "+v"(acc2[i]));
+        }
     }
     asm volatile("s_nop 4");
     // PAT 0: lane-linear 1 KB rows.  PAT 1: k_trunk_w6's round-3 image -- tile (position, row) pr = lane & 15 at pr * 3 KB, the
@@ -87,6 +95,11 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
                 SB; mf(wh, xh[sl], acc[i]); SB;
                 if (READS >= 2) rd(xl[nx], PAT == 1 ? (const char*)((size_t)p ^ 128) : p + (PAT >= 100 ? LOOFF : 1024));
                 SB; mf(wl, xh[sl], acc[i]); SB;
+                if (RB == 2) {
+                    SB; mf(wh2, xl[sl], acc2[i]); SB;
+                    SB; mf(wh2, xh[sl], acc2[i]); SB;
+                    SB; mf(wl2, xh[sl], acc2[i]); SB;
+                }
             } else {
                 const int sl2 = (i + 1) % 3, nx2 = i % 3;
                 SB; mf(wh, xl[sl], acc[i]); SB;
@@ -105,25 +118,25 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
     const unsigned long long t1 = clk();
     float r = 0.f;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) r += acc[i][0] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) r += acc[i][0] + acc[i][3] + (RB == 2 ? acc2[i][1] : 0.f);
     if (r == 12345.678f) sink[0] = r;
     if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int READS, int ASM, bool ILV, bool B64, int NACC, int PAT = 0, int WOFF = 1280, int SSTR = 8192, int SMOD = 3, int LOOFF = 1024>
+template <int READS, int ASM, bool ILV, bool B64, int NACC, int PAT = 0, int WOFF = 1280, int SSTR = 8192, int SMOD = 3, int LOOFF = 1024, int RB = 1>
 static void run(const char* name, int waves_per_simd, unsigned long long* d, float* sink) {
     const int steps = 36 * 60, threads = 256 * waves_per_simd;
-    hipFuncSetAttribute((const void*)k<READS, ASM, ILV, B64, NACC, PAT, WOFF, SSTR, SMOD, LOOFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    hipFuncSetAttribute((const void*)k<READS, ASM, ILV, B64, NACC, PAT, WOFF, SSTR, SMOD, LOOFF, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(d, 0, 256 * 8 * 8);
-        hipLaunchKernelGGL((k<READS, ASM, ILV, B64, NACC, PAT, WOFF, SSTR, SMOD, LOOFF>), dim3(256), dim3(threads), 147456, 0, d, sink, steps);
+        hipLaunchKernelGGL((k<READS, ASM, ILV, B64, NACC, PAT, WOFF, SSTR, SMOD, LOOFF, RB>), dim3(256), dim3(threads), 147456, 0, d, sink, steps);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); return; }
     }
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0, mx = 0; int n = 0;
     for (auto v : h) if (v) { sum += (double)v; mx = mx > (double)v ? mx : (double)v; ++n; }
-    const double mfmas_per_wave = 3.0 * steps;
+    const double mfmas_per_wave = 3.0 * RB * steps;
     printf("%-66s %d wave/SIMD: %6.2f cycles per MFMA per wave (mean), %6.2f per MFMA of the SIMD (slowest wave)\n", name, waves_per_simd,
            sum / n / mfmas_per_wave, mx / (mfmas_per_wave * waves_per_simd));
 }
@@ -131,6 +144,14 @@ static void run(const char* name, int waves_per_simd, unsigned long long* d, flo
 int main() {
     unsigned long long* d; float* sink;
     hipMalloc(&d, 256 * 8 * 8); hipMalloc(&sink, 4);
+    // the 8x8 trunk's question (round 4): today's wave (16 channels: 16 accumulators in VGPRs, two waves per SIMD, two
+    // reads per three MFMAs) against a 32-channel wave (32 accumulators, one wave per SIMD, two reads per SIX MFMAs)
+    run<2, 1, false, false, 16>("16-channel wave: asm VGPR acc, 16 acc, 2 reads / 3 MFMAs", 2, d, sink);
+    run<2, 0, false, false, 16>("16-channel wave: builtin, 16 acc, 2 reads / 3 MFMAs", 2, d, sink);
+    run<2, 0, false, false, 16, 0, 1280, 8192, 3, 1024, 2>("32-channel wave: builtin, 2 x 16 acc, 2 reads / 6 MFMAs", 1, d, sink);
+    run<2, 2, false, false, 16, 0, 1280, 8192, 3, 1024, 2>("32-channel wave: asm AGPR acc, 2 x 16 acc, 2 reads / 6 MFMAs", 1, d, sink);
+    run<2, 1, false, false, 16, 0, 1280, 8192, 3, 1024, 2>("32-channel wave: asm VGPR acc, 2 x 16 acc, 2 reads / 6 MFMAs", 1, d, sink);
+    run<0, 0, false, false, 16, 0, 1280, 8192, 3, 1024, 2>("32-channel wave: builtin, 2 x 16 acc, no reads", 1, d, sink);
     for (int w = 1; w <= 2; ++w) {
         run<0, 0, false, false, 36>("builtin (VGPR), 36 acc, no reads", w, d, sink);
         run<2, 0, false, false, 36>("builtin (VGPR), 36 acc, 2 ds_read_b128 / step, lane-linear", w, d, sink);
