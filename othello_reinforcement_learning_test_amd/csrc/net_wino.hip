@@ -1081,7 +1081,8 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     const int tp = tpe ? (atoi(tpe) == 1 ? 1 : 2) : (n <= 256 ? 1 : 2);
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
     static const int persist = getenv("OTH_WINO_PERSIST") ? atoi(getenv("OTH_WINO_PERSIST")) : 0;
-    static const bool w32 = getenv("OTH_WINO32") && atoi(getenv("OTH_WINO32")) == 1;
+    const char* e32 = getenv("OTH_WINO32");   // read per call: the variants test toggles it
+    const bool w32 = e32 && atoi(e32) == 1;
     if (w32 && tp == 2) {   // experiment: 32 channels per wave, four waves
         static bool a32[64] = {};
         if (!a32[net->device & 63]) {
