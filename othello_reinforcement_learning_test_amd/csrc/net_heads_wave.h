@@ -27,7 +27,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // the 2x32 kernel (in-kernel stamps, round 3).
 // WIDE (round 4, k_trunk_w6): batches of 36 loads instead of 12-16.  A wave alone on its SIMD hides nothing, so every batch
 // is one exposed L2 round trip (~700 cycles): on 6x6 the FCs are 18 batches (21 k cycles per wave for two positions, 10 % of
-// k_trunk_w6); with 36 per batch they are 6.  Only for kernels with registers to spare (512 per lane there).
+// k_trunk_w6); with 36 per batch they are 6 (8x8: 32 per batch).  Only for kernels with registers to spare; used by k_trunk_w6
+// (tried on the 64- / 128-filter builds of k_trunk_h3: no change).
 template <int F, int BS, int P, bool WIDE = false>
 __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* __restrict__ pfc_wt,
                                              const float* __restrict__ vfc1_wt, const float* const (&src)[P],
@@ -35,7 +36,7 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
                                              float* const (&vout)[P], const bool (&live)[P]) {
     constexpr int CELLS = BS * BS, NP = CELLS + 1, NI = 2 * CELLS;
     constexpr int U1 = 16;                                  // channels per batch (F is a multiple of 16)
-    constexpr int U2 = WIDE && NI % 36 == 0 ? 36 : (NI % 16 == 0 ? 16 : 12);   // policy FC inputs per batch (72 = 6 x 12, 128 = 8 x 16)
+    constexpr int U2 = WIDE ? (NI % 32 == 0 ? 32 : 36) : (NI % 16 == 0 ? 16 : 12);   // policy FC inputs per batch (72 = 6 x 12 / 2 x 36, 128 = 8 x 16 / 4 x 32)
     static_assert(F % U1 == 0 && NI % U2 == 0, "batch sizes must divide the trip counts");
     static_assert(NP <= 65, "one policy output per lane, plus at most one more");
 #ifdef OTH_HEADS_CHECK
@@ -179,7 +180,7 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
             for (int j = 0; j < 4; ++j) h[p][j] += hp.vfc1_b[lane + 64 * j];
     }
 #else
-    constexpr int U4 = WIDE && CELLS % 36 == 0 ? 36 : (CELLS % 16 == 0 ? 16 : 12);
+    constexpr int U4 = WIDE ? (CELLS % 32 == 0 ? 32 : 36) : (CELLS % 16 == 0 ? 16 : 12);
     static_assert(CELLS % U4 == 0, "batch size must divide the trip count");
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
