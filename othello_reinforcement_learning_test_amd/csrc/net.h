@@ -96,6 +96,7 @@ int wino6_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, c
                   const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 int wino_pack_weights(oth_net* net);  // net_wino.hip
 void wino_free_weights(oth_net* net);
+int wino_positions_per_workgroup(int64_t n);   // 1 or 2: which k_trunk_w build a launch of n positions runs
 int wino_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,
                  const int32_t* n_valid, float* logp, float* v, hipStream_t stream);
 int f32_pack_weights(oth_net* net);  // net_f32.hip

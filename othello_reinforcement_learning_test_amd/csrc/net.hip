@@ -159,7 +159,7 @@ int oth_net_kernel_info(const oth_net* net, int64_t n, char* name, int32_t name_
         issued = 3.0 * (double)((P * cells + 15) / 16 * 16) / (double)(P * cells);
         cl = 3750.0;
     } else if (net->wino) {
-        k = n > 256 ? "k_trunk_w<2> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, two positions per workgroup)"
+        k = wino_positions_per_workgroup(n) == 2 ? "k_trunk_w<2> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, two positions per workgroup)"
                     : "k_trunk_w<1> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, one position per workgroup)";
         issued = 3.0 * 2.0 / 3.0;
         cl = 1875.0;

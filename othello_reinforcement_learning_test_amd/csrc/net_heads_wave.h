@@ -39,9 +39,6 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
     constexpr int U2 = WIDE ? (NI % 32 == 0 ? 32 : 36) : (NI % 16 == 0 ? 16 : 12);   // policy FC inputs per batch (72 = 6 x 12 / 2 x 36, 128 = 8 x 16 / 4 x 32)
     static_assert(F % U1 == 0 && NI % U2 == 0, "batch sizes must divide the trip counts");
     static_assert(NP <= 65, "one policy output per lane, plus at most one more");
-#ifdef OTH_HEADS_CHECK
-    float keep_v[P], keep_p[P];
-#endif
     {   // 1x1 convs (+ folded BN) + ReLU: lane = cell
         float a0[P], a1[P], av[P];
 #pragma unroll
@@ -69,10 +66,6 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
             scratch[p * 192 + lane] = fmaxf(a0[p] + hp.pconv_b[0], 0.f);        // flatten order (channel, cell): net.py:88
             scratch[p * 192 + 64 + lane] = fmaxf(a1[p] + hp.pconv_b[1], 0.f);
             scratch[p * 192 + 128 + lane] = fmaxf(av[p] + hp.vconv_b[0], 0.f);
-#ifdef OTH_HEADS_CHECK
-            keep_v[p] = fmaxf(av[p] + hp.vconv_b[0], 0.f);
-            keep_p[p] = fmaxf(a0[p] + hp.pconv_b[0], 0.f);
-#endif
         }
     }
     // policy FC: lane = output (lanes >= NP idle); the 65th output of an 8x8 board is a wave reduction over the inputs
@@ -120,66 +113,11 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
     // routed to the low lane -- and on gfx950 that operand form returns wrong results whenever ANOTHER wave of the same SIMD
     // is issuing MFMAs at the time (tools/probes/probe_pk_opsel.hip: 24-29 % of wave-results wrong beside an MFMA partner,
     // none beside an idle / LDS / VALU / VMEM partner, none ever for the low-dword broadcast `op_sel_hi:[1,0,1]` or for
-    // plain pairs; in this kernel, builds differing in nothing but that operand form: OTH_HEADS_BATCH4 = 6 / 7 / 8 below,
-    // profiles/r04_heads_batch4_variants.txt).  The 64-filter builds had the same instructions and never failed: they
+    // plain pairs; in this kernel, eight builds differing in nothing but that operand form: profiles/r04_heads_batch4_variants.txt --
+    // the batched form itself was removed from this file in round 5, it is in the history at 274f240).  The 64-filter builds had the same instructions and never failed: they
     // run one wave per SIMD.  The library is therefore built with -fno-slp-vectorize (hipcc emits no packed fp32 of its
     // own; measured equal or faster), net_epilogue.h's packed arithmetic uses plain pairs, and
     // tools/check_mfma_hazards.py fails the build on any packed-fp32 instruction with a high-to-low operand select.
-#ifdef OTH_HEADS_BATCH4   // the form that misbehaved (kept buildable for the ISA comparison and the discriminating variants:
-                          // tools/probes/heads_batch4_variants.sh).  OTH_HEADS_BATCH4 = 1: as it was; 2: no packed fp32 (the
-                          // FMAs pinned scalar); 3: 4 rows per batch (16 loads in flight); 4: biases added after the loop
-                          // (the accumulators are not destinations of in-flight loads); 5: vmcnt(0) between loads and FMAs
-    constexpr int U3 = OTH_HEADS_BATCH4 == 3 ? 4 : (CELLS % 16 == 0 ? 8 : 6);   // value FC1 inputs per batch (x 4 outputs per lane)
-    static_assert(CELLS % U3 == 0, "batch size must divide the trip count");
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[p][j] = OTH_HEADS_BATCH4 == 4 ? 0.f : hp.vfc1_b[lane + 64 * j];
-#pragma unroll 1   // a batch is the unit: unrolled further, hipcc hoists every load and spills
-    for (int i0 = 0; i0 < CELLS; i0 += U3) {
-        float w[U3][4];
-#pragma unroll
-        for (int u = 0; u < U3; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[u][j] = vfc1_wt[(size_t)(i0 + u) * 256 + lane + 64 * j];
-        if (OTH_HEADS_BATCH4 == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < U3; ++u)
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float x = scratch[p * 192 + 128 + i0 + u];
-                if (OTH_HEADS_BATCH4 >= 6) {
-                    // the packed FMAs written out, so that the broadcast form is ours to choose: 6 = x in the LOW dword of
-                    // its pair, op_sel_hi:[1,0,1]; 7 = x in the HIGH dword, op_sel:[0,1,0]; 8 = {x, x}, no operand select
-                    using f2 = float __attribute__((ext_vector_type(2)));
-                    f2 xx = OTH_HEADS_BATCH4 == 6 ? f2{x, 0.f} : OTH_HEADS_BATCH4 == 7 ? f2{0.f, x} : f2{x, x};
-                    asm volatile("" : "+v"(xx));
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        f2 acc = {h[p][2 * jj], h[p][2 * jj + 1]};
-                        const f2 ww = {w[u][2 * jj], w[u][2 * jj + 1]};
-                        if (OTH_HEADS_BATCH4 == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(ww), "v"(xx));
-                        else if (OTH_HEADS_BATCH4 == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(ww), "v"(xx));
-                        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(ww), "v"(xx));
-                        h[p][2 * jj] = acc.x;
-                        h[p][2 * jj + 1] = acc.y;
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h[p][j] = fmaf(w[u][j], x, h[p][j]);
-                    if (OTH_HEADS_BATCH4 == 2) asm volatile("" : "+v"(h[p][j]));
-                }
-            }
-    }
-    if (OTH_HEADS_BATCH4 == 4) {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h[p][j] += hp.vfc1_b[lane + 64 * j];
-    }
-#else
     constexpr int U4 = WIDE ? (CELLS % 32 == 0 ? 32 : 36) : (CELLS % 16 == 0 ? 16 : 12);
     static_assert(CELLS % U4 == 0, "batch size must divide the trip count");
 #pragma unroll 1
@@ -205,7 +143,6 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
             h[p][3] = j == 3 ? hj[p] : h[p][3];
         }
     }
-#endif
     float w2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) w2[j] = hp.vfc2_w[lane + 64 * j];
@@ -226,15 +163,7 @@ __device__ __forceinline__ void heads_wave_n(const HeadParams& hp, const float* 
         if (live[p]) {
             if (lane < NP && lane < 64) lp[p][lane] = l0 - m - lse;
             if (NP > 64 && lane == 0) lp[p][64] = l64 - m - lse;
-#ifdef OTH_HEADS_CHECK
-            {   // diagnostic: has this wave's scratch changed since it was written?
-                const bool bv = scratch[p * 192 + 128 + lane] != keep_v[p], bp = scratch[p * 192 + lane] != keep_p[p];
-                const unsigned long long mv = __ballot(bv), mp = __ballot(bp);
-                if (lane == 0) *vout[p] = (mv || mp) ? 100.f + (mv ? 1.f : 0.f) + (mp ? 2.f : 0.f) : tanhf(tot + hp.vfc2_b[0]);
-            }
-#else
             if (lane == 0) *vout[p] = tanhf(tot + hp.vfc2_b[0]);
-#endif
         }
     }
 }

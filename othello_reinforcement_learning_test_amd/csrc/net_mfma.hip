@@ -116,14 +116,8 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
                                                   const uint64_t* __restrict__ lgl, int64_t n,
                                                   const int32_t* __restrict__ n_valid, float* __restrict__ logp,
                                                   float* __restrict__ vout) {
-#ifndef OTH_PD_X3
-#define OTH_PD_X3 2
-#endif
-#ifndef OTH_PB_X3
-#define OTH_PB_X3 2
-#endif
-    constexpr int PD = X3 ? OTH_PD_X3 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
-    constexpr int PB = X3 ? OTH_PB_X3 : 4;  // weight fragments in flight (k-steps)
+    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
+    constexpr int PB = X3 ? 2 : 4;  // weight fragments in flight (k-steps)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int64_t nv = n;
     if (n_valid) {
@@ -367,14 +361,10 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 template <bool INPLACE = true>
 __device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c) {
     if constexpr (!INPLACE) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#ifndef OTH_BUILTIN_MFMA
     // accumulate IN PLACE (vDst = SrcC): the register allocator otherwise moves an accumulator to fresh registers at
     // the head of a chain and pays WAR wait states (s_nop) when the freed registers are reused at once
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     return c;
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
 }
 // Chunk swizzle: within a ds_read_b128 lane group the two chunk indices differ in bit 0 and the cells split as
 // {(pos 0, x lo), (pos 1, x hi)} vs {(pos 0, x hi), (pos 1, x lo)} (x lo/hi = the two halves of the 8 shifted
@@ -396,12 +386,6 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                                                                    const uint64_t* __restrict__ lgl, int64_t n,
                                                                    const int32_t* __restrict__ n_valid,
                                                                    float* __restrict__ logp, float* __restrict__ vout) {
-#ifndef OTH16_PD
-#define OTH16_PD 2
-#endif
-#ifndef OTH16_PB
-#define OTH16_PB 1   // one k-step (8 tiles x 6 MFMAs = 768+ cycles) ahead covers the L2 latency; 2 spills registers
-#endif
     // in-place asm MFMAs only in the build that gains from them and that tools/check_mfma_hazards.py finds clean (TP = 2):
     // the 4-position build keeps some accumulators in AGPRs and copies MFMA results there at once, which needs the
     // compiler's own wait states
@@ -409,16 +393,12 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
     // the interleaved issue order pays where two workgroups share a CU and saturate the matrix pipe (TP = 2: -3 %); the
     // low-latency one-position build (launches <= 256 positions, a CU per workgroup) is 2-4 % faster with round 2's
     // clumped order and builtin MFMAs (same-session A/B, profiles/r03_trunk_experiments.log), so it keeps them
-#ifdef OTH_CLUMPED
-    constexpr bool ILV = false;
-#else
     constexpr bool ILV = TP == 2;
-#endif
-    constexpr int PD = (X3 || TP <= 2) ? OTH16_PD : 4;  // activation fragments in flight (tiles of 16 cells)
+    constexpr int PD = (X3 || TP <= 2) ? 2 : 4;  // activation fragments in flight (tiles of 16 cells)
     // weight k-steps (32 channels) in flight: a k-step is NT tiles x 6 MFMAs, i.e. 768 cycles at TP = 2 (one ahead covers
     // the L2 latency; two spill registers) but only 384 at TP = 1, where one ahead stalls every k-step (small engines
     // lost 25-30 % with it) and registers are plentiful
-    constexpr int PB = TP == 1 ? 2 : OTH16_PB;
+    constexpr int PB = TP == 1 ? 2 : 1;   // (TP = 2: one k-step -- 8 tiles x 6 MFMAs = 768+ cycles -- ahead covers the L2 latency; 2 spills registers)
     constexpr int NT = 4 * TP;      // 16-cell tiles per workgroup: (pair of positions) x (board row); TP = 1: two rows
     constexpr int ZERO_OFF = TP * 64 * kCellBytes;   // zero cell (512 B) after the activations
     constexpr int SCR_OFF = ZERO_OFF + 512;          // stem im2col (TP*4 KiB) / head scratch
@@ -609,11 +589,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
             constexpr int DY = decltype(DYC)::value;
             constexpr int NTV = (DY == 0 || TP == 1) ? NT : NT - NT / 8;  // tiles with in-board source rows
             constexpr int NQ = 4 * NTV;                      // (k-step, tile) fragments of one tap
-#ifdef OTH_ABLATE_TAPS   // diagnostic: 2 of 3 column taps (1.5x fewer MFMAs, everything else unchanged; WRONG results)
-            for (int dxi = 0; dxi < 2; ++dxi) {
-#else
             for (int dxi = 0; dxi < 3; ++dxi) {
-#endif
                 const int tap = (DY + 1) * 3 + dxi;
                 const int xs = cx + dxi - 1;
                 const bool xok = xs >= 0 && xs < 8;
@@ -670,11 +646,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                         acc[t][0] = mfma32<IP>(wlo[0], xh[sl], acc[t][0]);
                         OTH_SB;
                         if (pf) xh[psl] = *(const half8*)src;
-#ifdef OTH_ABLATE_W       // diagnostic: half the L2 -> CU weight stream (lo fragments not loaded; WRONG results)
-                        if (neww) wq[wslot][1] = wq[wslot][0];
-#else
                         if (neww) wq[wslot][1] = wl[(size_t)nstep * 1024 + 64];
-#endif
                         OTH_SB;
                         acc[t][1] = mfma32<IP>(wlo[1], xh[sl], acc[t][1]);
                         OTH_SB;
@@ -683,11 +655,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
                         OTH_SB;
                         acc[t][1] = mfma32<IP>(wh[1], xh[sl], acc[t][1]);
                         OTH_SB;
-#ifdef OTH_ABLATE_W
-                        if (neww) wq[wslot][3] = wq[wslot][2];
-#else
                         if (neww) wq[wslot][3] = wl[(size_t)nstep * 1024 + 192];
-#endif
                         OTH_SB;
                         acc[t][1] = mfma32<IP>(wh[1], xl[sl], acc[t][1]);
                     } else {

@@ -211,8 +211,8 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
 // low-latency build for launches of <= 256 positions (every workgroup has a CU to itself there): eight waves still
 // split the 128 channels, so a position's layer is 288 MFMAs per wave instead of the direct kernel's 792 on four.
 // Both builds sum every accumulator in the same order: a position's outputs do not depend on the launch size.
-template <int TP, bool PERSIST = false>
-__global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, const uint64_t* __restrict__ sb,
+template <int TP>
+__global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* __restrict__ sb,
                                                     const uint64_t* __restrict__ ob, const uint64_t* __restrict__ lgl,
                                                     int64_t n, const int32_t* __restrict__ n_valid,
                                                     float* __restrict__ logp, float* __restrict__ vout) {
@@ -226,15 +226,9 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
         nv = k < n ? k : n;
     }
     constexpr int NT = 2 * TP;   // N-tiles of a wave: (position, board half)
-    // A workgroup takes position group blockIdx.x.  PERSIST (OTH_WINO_PERSIST=g, round-4 experiment on the memory-side
-    // traffic): g workgroups loop over every g-th group, so that the weights pass each XCD's L2 once per launch instead of once
-    // per wave of workgroups.  A separate instantiation: the loop around the body costs the default build 324 spilled VGPRs.
-    for (int64_t blk = blockIdx.x; blk * TP < nv; blk += gridDim.x) {
-    const int64_t pos0 = blk * TP;
-    int tid_ = threadIdx.x;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid_));   // opaque per trip: nothing derived from it is hoisted out of the loop
-                                                             // (hoisted, the lane constants cost 324 spilled VGPRs)
-    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+    const int64_t pos0 = (int64_t)blockIdx.x * TP;   // a workgroup takes position group blockIdx.x
+    if (pos0 >= nv) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c = lane & 15;
     const int row4 = c >> 2, j = c & 3;        // row within the board half, tile column
     // N-tile nt = 2*p + h: position p, board half h; this lane's tile index within the position: 16*h + c
@@ -330,10 +324,7 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
     // at TP = 1, where the launch is one position per CU and bound by how many bytes of the weight stream (15.7 MB per
     // forward through ONE CU's vector-memory path), not by MFMAs: one position 0.177 -> 0.172 ms with 3 or 4 groups in flight
     // (6 spills: 0.259); the same loads with the non-temporal hint: 0.258 ms (they lose their L2 hits)
-#ifndef OTH_WRING1
-#define OTH_WRING1 4
-#endif
-    constexpr int RING = TP == 1 ? OTH_WRING1 : 2;
+    constexpr int RING = TP == 1 ? 4 : 2;
     static_assert(12 % RING == 0, "the ring index must be a compile-time function of the group");
     uint4 wq[RING][8];
 #ifdef OTH_STAMPS
@@ -387,12 +378,10 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
                         v1[h] = f32x2{__builtin_amdgcn_fmed3f(t1.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t1.y, 0.f, kWClamp)};
                     }
                 }
-#ifndef OTH_ABL_NOSAT
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0].x), __float_as_uint(v0[0].y)),
                                              max(__float_as_uint(v0[1].x), __float_as_uint(v0[1].y))));
                 sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0].x), __float_as_uint(v1[0].y)),
                                              max(__float_as_uint(v1[1].x), __float_as_uint(v1[1].y))));
-#endif
                 if (!last) {
                     f32x2 V[4][2];
 #pragma unroll
@@ -412,12 +401,8 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
                         lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
                         lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
                         char* dst = lds + wr_off[nt] + xi * kWTile;
-#ifdef OTH_ABL_NOWRITE   // timing ablation only (wrong results): no V stores; the values stay live through a dummy use
-                        asm volatile("" :: "v"(hi), "v"(lo), "v"(dst));
-#else
                         *(uint2*)dst = hi;
                         *(uint2*)(dst + 256) = lo;
-#endif
                     }
                 }
                 OTH_WSB;   // one N-tile at a time
@@ -464,13 +449,7 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
             const int xi = q & 3, nt = (q >> 2) % NT, grp = q / GS, kk = grp & 3, d = grp >> 2;
             return lds + rd_base[nt][d] + ((uint32_t)(kk << 6) ^ rd_key[d]) + xi * kWTile;
         };
-#ifndef OTH_WPD
-#define OTH_WPD 2
-#endif
-#ifndef OTH_WLD0
-#define OTH_WLD0 0
-#endif
-        constexpr int PD = OTH_WPD;   // LDS operand pairs in flight ahead of the MFMAs (steps)
+        constexpr int PD = 2;   // LDS operand pairs in flight ahead of the MFMAs (steps)
         half8 xh[PD + 1], xl[PD + 1];
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
@@ -493,19 +472,11 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
                 if (q < GS) acc[xi][nt] = wmfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = wmfma(wh, xl[sl], acc[xi][nt]);
                 OTH_WSB;
-#ifdef OTH_ABL_HALFLDS   // timing ablation only (wrong results): every second step reuses stale operand registers
-                if (q + PD < QT && ((q + PD) & 1) == 0) xh[psl] = *(const half8*)src_of(q + PD);
-#else
                 if (q + PD < QT) xh[psl] = *(const half8*)src_of(q + PD);
-#endif
                 OTH_WSB;
                 acc[xi][nt] = wmfma(wh, xh[sl], acc[xi][nt]);
                 OTH_WSB;
-#ifdef OTH_ABL_HALFLDS
-                if (q + PD < QT && ((q + PD) & 1) == 0) xl[psl] = *(const half8*)(src_of(q + PD) + 256);
-#else
                 if (q + PD < QT) xl[psl] = *(const half8*)(src_of(q + PD) + 256);
-#endif
                 // next group's fragments, one per step, as early as the ring allows (its other half is free from the
                 // group's first step on): at TP = 2 that is >= 8 steps = 770+ cycles of cover for the L2 latency (issued
                 // at steps 4..11 both waves of a SIMD stalled ~300 cycles at every group boundary)
@@ -516,13 +487,8 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
                     b4n = *(const float4*)(a.bias + (layer + 1) * 128 + ch0);
                     invn = a.inv[layer + 1];
                 }
-#ifdef OTH_ABL_HALFW   // timing ablation only (wrong results): every second weight fragment keeps its stale registers
-                if (step >= OTH_WLD0 && step < OTH_WLD0 + 8 && ((step - OTH_WLD0) & 1) == 0)
-#else
-                if (step >= OTH_WLD0 && step < OTH_WLD0 + 8)
-#endif
-                    wq[(grp + RING - 1) % RING][step - OTH_WLD0] =
-                        wl[(size_t)(grp + RING - 1) * (8 * 8 * 64) + (size_t)(step - OTH_WLD0) * 64];
+                if (step < 8)
+                    wq[(grp + RING - 1) % RING][step] = wl[(size_t)(grp + RING - 1) * (8 * 8 * 64) + (size_t)step * 64];
                 OTH_WSB;
                 acc[xi][nt] = wmfma(wlo, xh[sl], acc[xi][nt]);
                 OTH_WSB;
@@ -579,367 +545,6 @@ __global__ __launch_bounds__(512, PERSIST ? 1 : 2) void k_trunk_w(WinoArgs a, co
     heads_block2(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), TP == 2 && pos0 + 1 < nv,
                  logp + pos0 * 65, vout + pos0);
 #endif
-    if constexpr (!PERSIST) return;   // one trip: no loop in the default build
-    __syncthreads();   // the heads are done with the LDS planes before the next group's stem input overwrites them
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_trunk_w32 (round-4 experiment, OTH_WINO32=1): the same network, arithmetic, LDS image and weight
-// array as k_trunk_w<2>, with 32 output channels per wave -- four waves (one per SIMD) instead of eight.  A wave's operand
-// pair (hi, lo of V) then feeds SIX MFMAs (two 16-channel row blocks) instead of three, i.e. half the ds_read_b128 per MFMA:
-// the half-reads ablation of k_trunk_w bounds what that is worth at 5.7 % (same cycles, more clock), and the lone-wave
-// micro-benchmark (tools/probes/probe_w6_step.hip) says the step itself costs a lone wave nothing (16.3-16.5 cycles per MFMA).
-// 32 accumulators + 16 residual registers + a 32-fragment weight ring: ~390 registers, so builtin MFMAs (hipcc keeps the
-// hazards and chooses the register files).  Heads by a 256-thread copy of heads_block2.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void heads_block2_t256(const HeadParams& hp, const float* __restrict__ pfc_wt,
-                                                  const float* __restrict__ vfc1_wt, const float* act, float* scratch, bool live1,
-                                                  float* __restrict__ logp, float* __restrict__ vout) {
-    float* w3 = scratch;             // [128][3]
-    float* feat = scratch + 384;     // [2 positions][192]
-    float* h1 = scratch + 768;       // [2][256]
-    float* lgp = scratch + 1280;     // [2][2][72]
-    for (int t = threadIdx.x; t < 384; t += 256) {
-        const int i = t / 3, k = t % 3;
-        w3[t] = k < 2 ? hp.pconv_w[i * 2 + k] : hp.vconv_w[i];
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 384; t += 256) {
-        const int p = t / 192, rem = t % 192, k = rem >> 6, cell = rem & 63;
-        const float* a = act + (size_t)(p * 64 + cell) * kHeadRow;
-        float p0 = 0.f, p1 = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < 128; i += 2) {
-            p0 = fmaf(a[i], w3[i * 3 + k], p0);
-            p1 = fmaf(a[i + 1], w3[(i + 1) * 3 + k], p1);
-        }
-        float acc = p0 + p1;
-        acc += k < 2 ? hp.pconv_b[k] : hp.vconv_b[0];
-        feat[p * 192 + k * 64 + cell] = acc > 0.f ? acc : 0.f;
-    }
-    __syncthreads();
-    {   // value FC1: one output per thread, both positions
-        const int t = threadIdx.x;
-        float a0 = hp.vfc1_b[t], a1 = a0;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float w = vfc1_wt[i * 256 + t];
-            a0 = fmaf(w, feat[128 + i], a0);
-            a1 = fmaf(w, feat[192 + 128 + i], a1);
-        }
-        h1[t] = a0 > 0.f ? a0 : 0.f;
-        h1[256 + t] = a1 > 0.f ? a1 : 0.f;
-    }
-    if (threadIdx.x < 130) {   // policy FC: 65 outputs x two halves of the 128 inputs
-        const int u = threadIdx.x, o = u % 65, part = u / 65;
-        float s0 = part == 0 ? hp.pfc_b[o] : 0.f, s1 = s0;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float w = pfc_wt[(part * 64 + i) * 65 + o];
-            s0 = fmaf(w, feat[part * 64 + i], s0);
-            s1 = fmaf(w, feat[192 + part * 64 + i], s1);
-        }
-        lgp[part * 72 + o] = s0;
-        lgp[(2 + part) * 72 + o] = s1;
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {   // waves 0 and 1: log_softmax over the 65 logits and the fc2 dot product of their position
-        const int p = threadIdx.x >> 6, l = threadIdx.x & 63;
-        const float* gp = lgp + p * 2 * 72;
-        const float gl = gp[l] + gp[72 + l];
-        const float g64 = gp[64] + gp[72 + 64];
-        float m = fmaxf(gl, l == 0 ? g64 : -INFINITY);
-        for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        float s = expf(gl - m) + (l == 0 ? expf(g64 - m) : 0.f);
-        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-        const float lse = logf(s);
-        float acc = 0.f;
-        for (int i = l; i < 256; i += 64) acc = fmaf(hp.vfc2_w[i], h1[p * 256 + i], acc);
-        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
-        if (p == 0 || live1) {
-            logp[p * 65 + l] = gl - m - lse;
-            if (l == 0) {
-                logp[p * 65 + 64] = g64 - m - lse;
-                vout[p] = tanhf(acc + hp.vfc2_b[0]);
-            }
-        }
-    }
-}
-
-#ifndef OTH_W32_ASM
-#define OTH_W32_ASM 0   // 1: in-place asm MFMAs (VGPR accumulators) with the weight fragment as an AGPR operand
-#endif
-__device__ __forceinline__ f32x4 w32mfma(half8 a, half8 b, f32x4 c, bool first) {
-#if OTH_W32_ASM
-    if (first) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "a"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, first ? f32x4{0.f, 0.f, 0.f, 0.f} : c, 0, 0, 0);
-#endif
-}
-__global__ __launch_bounds__(256) void k_trunk_w32(WinoArgs a, const uint64_t* __restrict__ sb, const uint64_t* __restrict__ ob,
-                                                   const uint64_t* __restrict__ lgl, int64_t n, const int32_t* __restrict__ n_valid,
-                                                   float* __restrict__ logp, float* __restrict__ vout) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    int64_t nv = n;
-    if (n_valid) {
-        const int64_t k = *n_valid;
-        nv = k < n ? k : n;
-    }
-    constexpr int TP = 2, NT = 4, RB = 2;
-    const int64_t pos0 = (int64_t)blockIdx.x * TP;
-    if (pos0 >= nv) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g4 = lane >> 4, c = lane & 15;
-    const int row4 = c >> 2, j = c & 3;
-
-    // ---- stem input (as k_trunk_w)
-    if (tid < TP * 64) {
-        const int p = tid >> 6, cell = tid & 63, y = cell >> 3, x = cell & 7;
-        const bool live = pos0 + p < nv;
-        const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
-        const _Float16 one = (x & 1) ? (_Float16)(-kWActScale) : (_Float16)kWActScale;
-        _Float16 vals[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const int s = ok ? yy * 8 + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? one : (_Float16)0.0f;
-        }
-        half8* dst = (half8*)(lds + tid * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            half8 t;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = vals[q * 8 + i];
-            dst[q] = t;
-        }
-    }
-    if (tid < 128) ((uint4*)(lds + kWZeroOff))[tid] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-
-    f32x4 acc[RB][4][NT];   // [row block][xi][N-tile]
-    f32x4 res[RB][NT][2];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            res[rb][nt][0] = res[rb][nt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[rb][1][nt] = acc[rb][2][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {   // stem conv: acc[0] = y0, acc[3] = -y1
-        const uint4* wp = a.stem + (size_t)(2 * wave + rb) * 2 * 64 + lane;
-        const half8 wh = __builtin_bit_cast(half8, wp[0]), wlo = __builtin_bit_cast(half8, wp[64]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int cell = (nt >> 1) * 64 + ((nt & 1) * 4 + row4) * 8 + 2 * j + e;
-                const half8 xh = *(const half8*)(lds + cell * 64 + g4 * 16);
-                const f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc[rb][3 * e][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, t, 0, 0, 0);
-            }
-    }
-
-    int ch0[RB];
-    uint32_t wr_off[RB][NT];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int w8 = 2 * wave + rb;                 // the 16-channel row block = k_trunk_w's wave index
-        ch0[rb] = w8 * 16 + 4 * g4;
-        const uint32_t wchunk = (uint32_t)(2 * w8 + (g4 >> 1));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const uint32_t tl = (uint32_t)((nt & 1) * 16 + c);
-            wr_off[rb][nt] = ((uint32_t)(nt >> 1) * 32 + tl) * (4 * kWTile) + ((wchunk ^ (tl & 15)) << 4) + 8u * (uint32_t)(g4 & 1);
-        }
-    }
-    uint32_t rd_base[NT][3], rd_key[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        rd_key[d] = ((uint32_t)((c + 4 * (d - 1)) & 15) << 4) ^ ((uint32_t)g4 << 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int y = (nt & 1) * 4 + row4 + (d - 1);
-            const int ts = (nt & 1) * 16 + c + 4 * (d - 1);
-            rd_base[nt][d] = (y >= 0 && y < 8) ? (uint32_t)((nt >> 1) * 32 + ts) * (4 * kWTile) : (uint32_t)kWZeroOff;
-        }
-    }
-    const float mask_l = j == 0 ? 0.f : 1.f, mask_r = j == 3 ? 0.f : 1.f;
-    const f32x2 mask_l2 = {mask_l, mask_l}, mask_r2 = {mask_r, mask_r};
-
-    const int n_layers = 1 + a.n_res_layers;
-    uint32_t sat_bits = 0;
-    uint4 wq[2][RB][8];   // weight ring: [group parity][row block][xi hi, xi lo]
-    float4 b4[RB], b4n[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) b4[rb] = b4n[rb] = *(const float4*)(a.bias + ch0[rb]);
-    float inv = a.inv[0], invn = inv;
-    for (int layer = 0; layer < n_layers; ++layer) {
-        const bool last = layer == n_layers - 1;
-        if (layer > 0) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) b4[rb] = b4n[rb];
-            inv = invn;
-        }
-        const f32x2 inv2 = {inv, inv};
-        const uint4* wl = a.w + (size_t)layer * (12 * 8 * 8 * 64) + (size_t)(2 * wave) * (8 * 64) + lane;   // + rb * (8 * 64)
-        auto epilogue = [&](auto SKIP) {
-            constexpr bool add_res = decltype(SKIP)::value;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x2 v0[2], v1[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x2 a0 = whalf(acc[rb][0][nt], h), a1 = whalf(acc[rb][1][nt], h), a2 = whalf(acc[rb][2][nt], h),
-                                    a3 = whalf(acc[rb][3][nt], h);
-                        const f32x2 bb = h == 0 ? f32x2{b4[rb].x, b4[rb].y} : f32x2{b4[rb].z, b4[rb].w};
-                        const f32x2 t0 = pk_fma(pk_add(pk_add(a0, a1), a2), inv2, bb);
-                        const f32x2 t1 = pk_fma(pk_sub(pk_sub(a1, a2), a3), inv2, bb);
-                        if (add_res) {
-                            f32x2 r0 = whalf(res[rb][nt][0], h), r1 = whalf(res[rb][nt][1], h);
-                            pk_add_relu_inplace(r0, t0, kWClamp);
-                            pk_add_relu_inplace(r1, t1, kWClamp);
-                            wsethalf(res[rb][nt][0], h, r0);
-                            wsethalf(res[rb][nt][1], h, r1);
-                            v0[h] = r0;
-                            v1[h] = r1;
-                        } else {
-                            v0[h] = f32x2{__builtin_amdgcn_fmed3f(t0.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t0.y, 0.f, kWClamp)};
-                            v1[h] = f32x2{__builtin_amdgcn_fmed3f(t1.x, 0.f, kWClamp), __builtin_amdgcn_fmed3f(t1.y, 0.f, kWClamp)};
-                        }
-                    }
-                    sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0].x), __float_as_uint(v0[0].y)),
-                                                 max(__float_as_uint(v0[1].x), __float_as_uint(v0[1].y))));
-                    sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0].x), __float_as_uint(v1[0].y)),
-                                                 max(__float_as_uint(v1[1].x), __float_as_uint(v1[1].y))));
-                    if (!last) {
-                        f32x2 V[4][2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const f32x2 dl = {quad_prev(v1[h].x), quad_prev(v1[h].y)};
-                            const f32x2 dr = {quad_next(v0[h].x), quad_next(v0[h].y)};
-                            V[0][h] = pk_fma_nc(dl, mask_l2, v1[h]);
-                            V[1][h] = pk_add(v0[h], v1[h]);
-                            V[2][h] = pk_sub(v1[h], v0[h]);
-                            V[3][h] = pk_fma_na(dr, mask_r2, v0[h]);
-                        }
-#pragma unroll
-                        for (int xi = 0; xi < 4; ++xi) {
-                            uint2 hi, lo;
-                            hi.x = wpack(V[xi][0].x, V[xi][0].y);
-                            hi.y = wpack(V[xi][1].x, V[xi][1].y);
-                            lo.x = wresid(hi.x, V[xi][0].x, V[xi][0].y);
-                            lo.y = wresid(hi.y, V[xi][1].x, V[xi][1].y);
-                            char* dst = lds + wr_off[rb][nt] + xi * kWTile;
-                            *(uint2*)dst = hi;
-                            *(uint2*)(dst + 256) = lo;
-                        }
-                    }
-                    OTH_WSB;
-                }
-        };
-        using T_ = std::true_type;
-        using F_ = std::false_type;
-        if (layer == 0 && !last) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int f = 0; f < 8; ++f) wq[0][rb][f] = wl[(size_t)rb * (8 * 64) + (size_t)f * 64];
-        }
-        wbarrier();
-        if (layer & 1) epilogue(F_{});
-        else epilogue(T_{});
-        if (last) break;
-        wbarrier();
-
-        constexpr int GS = NT * 4, QT = 12 * GS, PD = 2;
-        auto src_of = [&](int q) -> const char* {
-            const int xi = q & 3, nt = (q >> 2) % NT, grp = q / GS, kk = grp & 3, d = grp >> 2;
-            return lds + rd_base[nt][d] + ((uint32_t)(kk << 6) ^ rd_key[d]) + xi * kWTile;
-        };
-        half8 xh[PD + 1], xl[PD + 1];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            xh[q] = *(const half8*)src_of(q);
-            xl[q] = *(const half8*)(src_of(q) + 256);
-        }
-        auto conv_d = [&](auto DC) {
-            constexpr int D = decltype(DC)::value;
-#pragma unroll
-            for (int ql = 0; ql < 4 * GS; ++ql) {
-                const int q = D * 4 * GS + ql;
-                const int xi = q & 3, nt = (q >> 2) % NT, grp = q / GS, sl = q % (PD + 1), psl = (q + PD) % (PD + 1), step = q % GS;
-                const half8 wh0 = __builtin_bit_cast(half8, wq[grp & 1][0][2 * xi]), wl0 = __builtin_bit_cast(half8, wq[grp & 1][0][2 * xi + 1]);
-                const half8 wh1 = __builtin_bit_cast(half8, wq[grp & 1][1][2 * xi]), wl1 = __builtin_bit_cast(half8, wq[grp & 1][1][2 * xi + 1]);
-                OTH_WSB;
-                acc[0][xi][nt] = w32mfma(wh0, xl[sl], acc[0][xi][nt], q < GS);
-                OTH_WSB;
-                if (q + PD < QT) xh[psl] = *(const half8*)src_of(q + PD);
-                OTH_WSB;
-                acc[1][xi][nt] = w32mfma(wh1, xl[sl], acc[1][xi][nt], q < GS);
-                OTH_WSB;
-                acc[0][xi][nt] = w32mfma(wh0, xh[sl], acc[0][xi][nt], false);
-                OTH_WSB;
-                if (q + PD < QT) xl[psl] = *(const half8*)(src_of(q + PD) + 256);
-                OTH_WSB;
-                acc[1][xi][nt] = w32mfma(wh1, xh[sl], acc[1][xi][nt], false);
-                OTH_WSB;
-                if (grp == 10 && step == GS / 2) {
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) b4n[rb] = *(const float4*)(a.bias + (layer + 1) * 128 + ch0[rb]);
-                    invn = a.inv[layer + 1];
-                }
-                // next group's sixteen fragments, one per step (grp = 11 loads group 0 of the NEXT convolution; zero groups pad the array)
-                wq[(grp + 1) & 1][step >> 3][step & 7] =
-                    wl[(size_t)(grp + 1) * (8 * 8 * 64) + (size_t)(step >> 3) * (8 * 64) + (size_t)(step & 7) * 64];
-                OTH_WSB;
-                acc[0][xi][nt] = w32mfma(wl0, xh[sl], acc[0][xi][nt], false);
-                OTH_WSB;
-                acc[1][xi][nt] = w32mfma(wl1, xh[sl], acc[1][xi][nt], false);
-                OTH_WSB;
-            }
-        };
-        conv_d(std::integral_constant<int, 0>{});
-        conv_d(std::integral_constant<int, 1>{});
-        conv_d(std::integral_constant<int, 2>{});
-#if OTH_W32_ASM
-        asm volatile("s_nop 7" ::: "memory");   // the last asm MFMA's result: 8 wait states before anything else touches it
-        OTH_WSB;
-#endif
-    }
-
-    // ---------------- heads
-    if (sat_bits >= __float_as_uint(kWClamp)) atomicOr(a.sat, 1);
-    __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int cell = (nt >> 1) * 64 + ((nt & 1) * 4 + row4) * 8 + 2 * j + e;
-                const float us = 1.0f / kWActScale;
-                const f32x4 v = res[rb][nt][e];
-                float* dst = (float*)lds + (size_t)cell * kHeadRow + ch0[rb];
-                dst[0] = v[0] * us;
-                dst[1] = v[1] * us;
-                dst[2] = v[2] * us;
-                dst[3] = v[3] * us;
-            }
-    __syncthreads();
-    heads_block2_t256(a.heads, a.pfc_wt, a.vfc1_wt, (const float*)lds, (float*)(lds + 128 * kHeadRow * 4 + 64), pos0 + 1 < nv,
-                      logp + pos0 * 65, vout + pos0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1050,6 +655,15 @@ int wino_pack_weights(oth_net* net) {
     return OTH_OK;
 }
 
+// Launches that cannot fill the chip (every workgroup has a CU to itself either way) run one position per workgroup; both
+// builds sum every accumulator in the same order, so a position's outputs do not depend on this.  OTH_WINO_TP=1|2 (read
+// per call) forces a build: the switch the variants test uses to compare the two on the same batch.  The ONE place the
+// decision is made: oth_net_kernel_info reports what this returns.
+int wino_positions_per_workgroup(int64_t n) {
+    const char* tpe = getenv("OTH_WINO_TP");
+    return tpe ? (atoi(tpe) == 1 ? 1 : 2) : (n <= 256 ? 1 : 2);
+}
+
 int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uint64_t* lg, int64_t n,
                  const int32_t* n_valid, float* logp, float* v, hipStream_t stream) {
     OTH_CHECK(net->wino, "Winograd weights not packed");
@@ -1076,31 +690,9 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kWLds));
         attr_set = true;
     }
-    // launches that cannot fill the chip (every workgroup has a CU to itself either way) run one position per workgroup
-    const char* tpe = getenv("OTH_WINO_TP");
-    const int tp = tpe ? (atoi(tpe) == 1 ? 1 : 2) : (n <= 256 ? 1 : 2);
+    const int tp = wino_positions_per_workgroup(n);
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
-    static const int persist = getenv("OTH_WINO_PERSIST") ? atoi(getenv("OTH_WINO_PERSIST")) : 0;
-    const char* e32 = getenv("OTH_WINO32");   // read per call: the variants test toggles it
-    const bool w32 = e32 && atoi(e32) == 1;
-    if (w32 && tp == 2) {   // experiment: 32 channels per wave, four waves
-        static bool a32[64] = {};
-        if (!a32[net->device & 63]) {
-            OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_w32, hipFuncAttributeMaxDynamicSharedMemorySize, kWLds));
-            a32[net->device & 63] = true;
-        }
-        hipLaunchKernelGGL(k_trunk_w32, dim3(grid), dim3(256), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
-        OTH_HIP(hipGetLastError());
-        return OTH_OK;
-    }
-    if (persist > 0 && tp == 2 && grid > (unsigned)persist) {   // experiment: `persist` looping workgroups
-        static bool pattr[64] = {};
-        if (!pattr[net->device & 63]) {
-            OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_w<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWLds));
-            pattr[net->device & 63] = true;
-        }
-        hipLaunchKernelGGL((k_trunk_w<2, true>), dim3((unsigned)persist), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    } else if (tp == 1) hipLaunchKernelGGL(k_trunk_w<1>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    if (tp == 1) hipLaunchKernelGGL(k_trunk_w<1>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
     else hipLaunchKernelGGL(k_trunk_w<2>, dim3(grid), dim3(512), kWLds, stream, a, sb, ob, lg, n, n_valid, logp, v);
     OTH_HIP(hipGetLastError());
 #ifdef OTH_STAMPS

@@ -93,42 +93,17 @@ __device__ __forceinline__ unsigned long long w6_realclk() {
 #define OTH_W6STAMP(i)
 #endif
 
-// MFMA forms.  The builtin (default): 36 accumulators + 18 residual registers + the weight ring need more than 256
-// architectural VGPRs; with the builtin the allocator keeps the accumulators in AGPRs (MFMA reads and writes them there) and
-// knows the hazards.  -DOTH_W6_ASM=1 (round-4 experiment, kept buildable): in-place asm MFMAs whose A operand -- the weight
-// fragment -- is an AGPR operand ("a": an MFMA reads A / B from either file), so that the weight ring (loaded from L2
-// straight into AGPRs: `global_load_dwordx4 a[..]`) and the residual live in the AGPR half and the 36 accumulators in VGPRs --
-// worth 2 cycles per MFMA for a lone wave in isolation (tools/probes/probe_w6_step.hip: 16.7 vs 18.7).  In the kernel:
-// convolution 120.4 k vs 122.7 k cycles, but hipcc parks all 36 accumulators in AGPRs around the epilogue anyway (288 copies
-// per layer instead of the builtin's 144 reads), so the launch is no faster (0.222 vs 0.222 ms, interleaved A/B) -- and the
-// form is fragile: the same source under the stamps build's register pressure gets accumulator copies right behind the asm
-// MFMAs (102 hazards by tools/check_mfma_hazards.py, and indeed wrong outputs: 2.4e-2).  Not shipped.
-#ifndef OTH_W6_ASM
-#define OTH_W6_ASM 0
-#endif
-#ifndef OTH_W6_ST128
-#define OTH_W6_ST128 0   // 1: 16-byte V stores through v_permlane16_swap (round-4 experiment: conflict-free, and slower -- epilogues
-                         // 47.8 k -> 63.3 k cycles, 0.214 -> 0.222 ms interleaved: a ds_write_b128 moves five source dwords to the LDS
-                         // at 13 cycles against 2 x 6 for the 8-byte pair, plus eight swaps per tile column)
-#endif
+// The MFMA builtin: 36 accumulators + 18 residual registers + the weight ring need more than 256 architectural VGPRs; with
+// the builtin the allocator keeps the accumulators in AGPRs (MFMA reads and writes them there) and knows the hazards.  (An
+// in-place inline-asm form with VGPR accumulators and AGPR weight operands was measured in round 4 -- no faster, and one build of
+// it miscompared with 102 hazards by tools/check_mfma_hazards.py: DESIGN_HISTORY.md K3d; removed from the sources in round 5.)
 __device__ __forceinline__ f32x4 w6mfma(u32x4 a4, half8 b, f32x4 c) {
     const half8 a = __builtin_bit_cast(half8, a4);
-#if OTH_W6_ASM
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ f32x4 w6mfma0(u32x4 a4, half8 b) {   // first product of a chain: C = 0
     const half8 a = __builtin_bit_cast(half8, a4);
-#if OTH_W6_ASM
-    f32x4 c;
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "a"(a), "v"(b));
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ void w6barrier() {   // LDS-only barrier: global weight prefetches stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -139,12 +114,10 @@ __device__ __forceinline__ void w6barrier() {   // LDS-only barrier: global weig
 
 // All 512 registers per lane: nothing else is resident on the CU beside this workgroup -- in the two-lane engine the other
 // lane's tree kernel (70 VGPRs) then runs after the trunk instead of beside it (trunk share of the step 0.98 -> 0.92).  Capped
-// at 440 / 400 registers (-DOTH_W6REGS=220 / 200) the tree kernel is back beside it, but the spills cost more: 17.6 k / 17.0 k
+// at 440 / 400 registers (k6Regs = 220 / 200) the tree kernel is back beside it, but the spills cost more: 17.6 k / 17.0 k
 // games/s on configs[4] against 23.1 k uncapped (k_trunk_h3: 21.9 k on the same box).
-#ifndef OTH_W6REGS
-#define OTH_W6REGS 256   // x 2 = total registers per lane (VGPR + AGPR)
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) void k_trunk_w6(Wino6Args a, const uint64_t* __restrict__ sb,
+constexpr int k6Regs = 256;   // x 2 = total registers per lane (VGPR + AGPR)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void k_trunk_w6(Wino6Args a, const uint64_t* __restrict__ sb,
                                                   const uint64_t* __restrict__ ob, const uint64_t* __restrict__ lgl,
                                                   int64_t n, const int32_t* __restrict__ n_valid, float* __restrict__ logp,
                                                   float* __restrict__ vout) {
@@ -243,13 +216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
     uint32_t rd_base[3][3];  // read address of (lane group, row tap): run 0 -- or the zero plane
 #pragma unroll
     for (int lg = 0; lg < 3; ++lg) {
-#if OTH_W6_ST128   // the whole slot; odd rows (g4 & 1) store xi + 2 (see the epilogue)
-        wr_off[lg] = (uint32_t)(lg * k6LgBytes + (2 * (wave & 1) + (g4 >> 1)) * k6PlaneBytes + k6_run(0, 0, wave >> 1, 0) + c * 16 +
-                                (g4 & 1) * (k6_run(0, 2, 0, 0) - k6_run(0, 0, 0, 0)));
-#else
         wr_off[lg] = (uint32_t)(lg * k6LgBytes + (2 * (wave & 1) + (g4 >> 1)) * k6PlaneBytes + k6_run(0, 0, wave >> 1, 0) + c * 16 +
                                 8 * (g4 & 1));
-#endif
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int rs = row_l[lg] + d - 1;
@@ -331,27 +299,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                             lo[xi].x = wresid(hi[xi].x, V[xi][0].x, V[xi][0].y);
                             lo[xi].y = wresid(hi[xi].y, V[xi][1].x, V[xi][1].y);
                         }
-#if OTH_W6_ST128
-                        // 16-byte stores: a lane holds 4 of the 8 channels of its column's slot, its partner 16 lanes away
-                        // (g4 ^ 1) the other 4.  v_permlane16_swap trades the xi = a words of the odd row against the xi = a + 2
-                        // words of the even row, so that the even lane ends up with all 8 channels of xi = a and the odd lane with
-                        // all 8 of xi = a + 2: one conflict-free ds_write_b128 each instead of two 2-way-conflicting ds_write_b64.
-#pragma unroll
-                        for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                const uint2 A = half ? lo[a2] : hi[a2], B = half ? lo[a2 + 2] : hi[a2 + 2];
-                                const auto s0 = __builtin_amdgcn_permlane16_swap(A.x, B.x, false, false);
-                                const auto s1 = __builtin_amdgcn_permlane16_swap(A.y, B.y, false, false);
-                                *(uint4*)(lds + wr_off[lg] + k6_run(j, a2, 0, half)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                            }
-#else
 #pragma unroll
                         for (int xi = 0; xi < 4; ++xi) {
                             *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 0)) = hi[xi];
                             *(uint2*)(lds + wr_off[lg] + k6_run(j, xi, 0, 1)) = lo[xi];
                         }
-#endif
                     }
                 }
                 OTH_W6SB;   // one lane group at a time (without it: no change)
@@ -380,27 +332,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         constexpr int GS = k6NT * 4;            // steps of a group
         constexpr int QT = k6Groups * GS;       // steps of a layer
         auto src_of = [&](int q, int half) -> uint32_t {
-#ifdef OTH_W6_ABL_LINEAR   // timing ablation (wrong results): every read a plain lane-linear 1 KB row
-            return (uint32_t)(wave * 32768 + (q & 15) * 2048 + half * 1024 + lane * 16);
-#endif
             const int xi = q & 3, nt = (q >> 2) % k6NT, grp = q / GS, kk = grp & 1, d = grp >> 1;
             return rd_base[nt / 3][d] + (uint32_t)k6_run(nt % 3, xi, kk, half);
         };
-#ifndef OTH_W6PD
-#define OTH_W6PD 2
-#endif
-        constexpr int PD = OTH_W6PD;   // LDS operand pairs in flight ahead of the MFMAs (steps)
+        constexpr int PD = 2;   // LDS operand pairs in flight ahead of the MFMAs (steps)
         half8 xh[PD + 1], xl[PD + 1];
-#if OTH_W6_ASM
-        // The first group's fragments are loop-carried (loaded in the previous layer's last group, or above for layer 0):
-        // hipcc reconciles their registers with v_accvgpr_mov copies which it sinks right in front of the first MFMAs --
-        // invisible hazards for asm MFMAs (tools/check_mfma_hazards.py flagged 14).  Pinned here, in the AGPR class, in
-        // front of the two wait states a VALU write needs before an MFMA reads it.
-#pragma unroll
-        for (int f = 0; f < 8; ++f) asm volatile("" : "+a"(wq[0][f]));
-        asm volatile("s_nop 1" ::: "memory");
-        OTH_W6SB;
-#endif
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
             xh[q] = *(const half8*)(lds + src_of(q, 0));
@@ -418,30 +354,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
                 if (q < GS) acc[xi][nt] = w6mfma0(wh, xl[sl]);     // the layer's first group starts every accumulator
                 else acc[xi][nt] = w6mfma(wh, xl[sl], acc[xi][nt]);
                 OTH_W6SB;
-#ifndef OTH_W6_ABL_NOLDS   // timing ablations (wrong results by construction): no operand reads / no weight loads
                 if (q + PD < QT) xh[psl] = *(const half8*)(lds + src_of(q + PD, 0));
-#else
-                asm volatile("" : "+v"(xh[psl]));   // opaque: the MFMAs stay
-#endif
                 OTH_W6SB;
                 acc[xi][nt] = w6mfma(wh, xh[sl], acc[xi][nt]);
                 OTH_W6SB;
-#ifndef OTH_W6_ABL_NOLDS
                 if (q + PD < QT) xl[psl] = *(const half8*)(lds + src_of(q + PD, 1));
-#else
-                asm volatile("" : "+v"(xl[psl]));
-#endif
                 if (grp == k6Groups - 2 && step == GS / 2) {
                     b4n = *(const float4*)(a.bias + (layer + 1) * k6F + ch0);
                     invn = a.inv[layer + 1];
                 }
                 // next group's fragments, one per step from the group's first step on (the last group loads group 0 of
                 // the NEXT convolution: the layers are contiguous and one zero group pads the end of the array)
-#ifndef OTH_W6_ABL_NOW
                 if (step < 8) wq[(grp + 1) & 1][step] = wl[(size_t)(grp + 1) * k6GroupU4 + (size_t)step * 64];
-#else
-                if (step < 8) asm volatile("" : "+v"(wq[(grp + 1) & 1][step]));
-#endif
                 OTH_W6SB;
                 acc[xi][nt] = w6mfma(wlo, xh[sl], acc[xi][nt]);
                 OTH_W6SB;
@@ -450,12 +374,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(OTH_W6REGS))) v
         conv_d(std::integral_constant<int, 0>{});
         conv_d(std::integral_constant<int, 1>{});
         conv_d(std::integral_constant<int, 2>{});
-#if OTH_W6_ASM
-        // the last asm MFMA's result needs 8 wait states before anything but an MFMA touches it, and hipcc -- which cannot
-        // see that -- may move accumulators right behind the loop's last instruction (the checker found one 6 states behind)
-        asm volatile("s_nop 3" ::: "memory");
-        OTH_W6SB;
-#endif
     }
 
     // ---------------- heads (fp32 VALU): final activations (in `res`, x 2^4) -> LDS planes [channel][8 x 36 cells] f32

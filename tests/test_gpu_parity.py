@@ -533,38 +533,6 @@ def test_wino6_variants_agree(pkg):
             os.environ["OTH_WINO6"] = old
 
 
-def test_wino32_variant_bit_identical(pkg):
-    """The 32-channel-per-wave build of the 8x8 Winograd trunk (k_trunk_w32, OTH_WINO32=1: a measured experiment, off by
-    default) shares k_trunk_w's weight array, LDS image and summation order: its outputs must be bit-identical, ragged
-    batch and device-side batch length included."""
-    import os
-    torch.manual_seed(5)
-    net = pkg.OthelloResNet(3, 128).eval()
-    rng = np.random.Generator(np.random.PCG64(23))
-    n = 777
-    occ = rng.random((n, 8, 8)) < 0.5
-    own = occ & (rng.random((n, 8, 8)) < 0.5)
-    x = torch.from_numpy(np.stack([own, occ & ~own, (~occ) & (rng.random((n, 8, 8)) < 0.4)], 1).astype(np.float32)).cuda()
-    ev = pkg.HipResNetEvaluator(net, precision="f16x3")
-    old = os.environ.get("OTH_WINO32")
-    try:
-        os.environ.pop("OTH_WINO32", None)
-        l0, v0 = ev.forward_planes(x)
-        torch.cuda.synchronize()
-        os.environ["OTH_WINO32"] = "1"
-        l1, v1 = ev.forward_planes(x)
-        torch.cuda.synchronize()
-    finally:
-        if old is None:
-            os.environ.pop("OTH_WINO32", None)
-        else:
-            os.environ["OTH_WINO32"] = old
-    with torch.no_grad():
-        rl, rv = net.cuda()(x)
-    assert torch.equal(l0, l1) and torch.equal(v0, v1)
-    assert (l0 - rl).abs().max().item() < 1e-4 and (v0 - rv).abs().max().item() < 1e-4
-
-
 @pytest.mark.parametrize("blocks,filters,board", [(2, 128, 8), (2, 64, 8), (2, 32, 6)])
 def test_trunk_saturation_is_surfaced(pkg, blocks, filters, board):
     """The fp16-split trunk kernels clamp activations at 3750; the reference's fp32 forward does not.  A network whose

@@ -10,7 +10,7 @@ Disassembles the gfx950 code object of every given .o (llvm-objdump) and fails i
       4-pass 16x16x32 f16, 12 for the 8-pass shapes),
   (3) any packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) selects the HIGH dword
       of a source pair for its LOW lane (`op_sel:[..1..]`): on gfx950 that operand form returns wrong results now and then
-      when two waves share a SIMD (round 4: tools/probes/probe_pk_opsel.hip, heads_batch4_variants.sh -- the cause of the
+      when two waves share a SIMD (round 4: tools/probes/probe_pk_opsel.hip, profiles/r04_heads_batch4_variants.txt -- the cause of the
       value-head errors of round 3).  hipcc's SLP vectoriser emits it for broadcast operands, so the library is built with
       -fno-slp-vectorize and its own packed arithmetic (net_epilogue.h) uses plain pairs only,
 (1) and (2) along straight-line code AND ACROSS EVERY BRANCH EDGE: for each s_branch / s_cbranch_* the tail window of the branch's

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Timing ablations and diagnostic forms of the trunk kernels, kept OUT of the product sources.
+
+Every entry below is a list of (file, search, replace) edits applied to a COPY of
+othello_reinforcement_learning_test_amd/csrc (tools/build_variant.sh --ablation NAME ... does the copy, the edit and the
+build).  Most of them give WRONG results by construction -- they exist to price one term of a kernel's time (DESIGN_HISTORY.md,
+sections K3w / K3 / K3d) -- so none of them is a `-D` away from a shipping library any more.
+
+usage: apply_ablation.py NAME SRCDIR      (NAME = one of the keys of ABLATIONS; `list` prints them)
+"""
+import os
+import sys
+
+ABLATIONS = {
+    # ---- k_trunk_w (net_wino.hip), round 3: what is left is power, not issue slots -------------------------------------
+    "wino_halflds": ("every second conv step reuses stale operand registers instead of reading LDS (WRONG results)", [
+        ("net_wino.hip", "                if (q + PD < QT) xh[psl] = *(const half8*)src_of(q + PD);",
+         "                if (q + PD < QT && ((q + PD) & 1) == 0) xh[psl] = *(const half8*)src_of(q + PD);"),
+        ("net_wino.hip", "                if (q + PD < QT) xl[psl] = *(const half8*)(src_of(q + PD) + 256);",
+         "                if (q + PD < QT && ((q + PD) & 1) == 0) xl[psl] = *(const half8*)(src_of(q + PD) + 256);"),
+    ]),
+    "wino_nowrite": ("no V stores in the epilogue; the values stay live through a dummy use (WRONG results)", [
+        ("net_wino.hip", "                        *(uint2*)dst = hi;\n                        *(uint2*)(dst + 256) = lo;",
+         '                        asm volatile("" :: "v"(hi), "v"(lo), "v"(dst));'),
+    ]),
+    "wino_halfw": ("every second weight fragment keeps its stale registers: half the L2 -> CU stream (WRONG results)", [
+        ("net_wino.hip", "                if (step < 8)\n                    wq[(grp + RING - 1) % RING][step] =",
+         "                if (step < 8 && (step & 1) == 0)\n                    wq[(grp + RING - 1) % RING][step] ="),
+    ]),
+    "wino_nosat": ("no saturation tracking in the epilogue (clamped activations would go unreported)", [
+        ("net_wino.hip", "                sat_bits = max(sat_bits, max(max(__float_as_uint(v0[0].x), __float_as_uint(v0[0].y)),\n"
+                         "                                             max(__float_as_uint(v0[1].x), __float_as_uint(v0[1].y))));\n"
+                         "                sat_bits = max(sat_bits, max(max(__float_as_uint(v1[0].x), __float_as_uint(v1[0].y)),\n"
+                         "                                             max(__float_as_uint(v1[1].x), __float_as_uint(v1[1].y))));\n", ""),
+    ]),
+    # ---- k_trunk16 (net_mfma.hip), round 3 -----------------------------------------------------------------------------
+    "mfma_taps": ("2 of 3 column taps: 1.5x fewer MFMAs, LDS reads and weight bytes, epilogue unchanged (WRONG results)", [
+        ("net_mfma.hip", "            for (int dxi = 0; dxi < 3; ++dxi) {\n                const int tap = (DY + 1) * 3 + dxi;",
+         "            for (int dxi = 0; dxi < 2; ++dxi) {\n                const int tap = (DY + 1) * 3 + dxi;"),
+    ]),
+    "mfma_halfw": ("the lo weight fragments are not loaded: half the L2 -> CU weight stream (WRONG results)", [
+        ("net_mfma.hip", "                        if (neww) wq[wslot][1] = wl[(size_t)nstep * 1024 + 64];",
+         "                        if (neww) wq[wslot][1] = wq[wslot][0];"),
+        ("net_mfma.hip", "                        if (neww) wq[wslot][3] = wl[(size_t)nstep * 1024 + 192];",
+         "                        if (neww) wq[wslot][3] = wq[wslot][2];"),
+    ]),
+    # ---- k_trunk_w6 (net_wino6.hip), round 4: the LDS image of V was the cost ------------------------------------------
+    "w6_linear": ("every operand read a plain lane-linear 1 KB row instead of the real addresses (WRONG results)", [
+        ("net_wino6.hip", "            const int xi = q & 3, nt = (q >> 2) % k6NT, grp = q / GS, kk = grp & 1, d = grp >> 1;\n"
+                          "            return rd_base[nt / 3][d] + (uint32_t)k6_run(nt % 3, xi, kk, half);",
+         "            return (uint32_t)(wave * 32768 + (q & 15) * 2048 + half * 1024 + lane * 16);"),
+    ]),
+    "w6_nolds": ("no operand reads; the registers are made opaque so that the MFMAs stay (WRONG results)", [
+        ("net_wino6.hip", "                if (q + PD < QT) xh[psl] = *(const half8*)(lds + src_of(q + PD, 0));",
+         '                asm volatile("" : "+v"(xh[psl]));'),
+        ("net_wino6.hip", "                if (q + PD < QT) xl[psl] = *(const half8*)(lds + src_of(q + PD, 1));",
+         '                asm volatile("" : "+v"(xl[psl]));'),
+    ]),
+    "w6_now": ("no weight loads; the ring registers are made opaque so that the MFMAs stay (WRONG results)", [
+        ("net_wino6.hip", "                if (step < 8) wq[(grp + 1) & 1][step] = wl[(size_t)(grp + 1) * k6GroupU4 + (size_t)step * 64];",
+         '                if (step < 8) asm volatile("" : "+v"(wq[(grp + 1) & 1][step]));'),
+    ]),
+}
+
+
+def apply(name, srcdir):
+    desc, edits = ABLATIONS[name]
+    for fname, search, replace in edits:
+        path = os.path.join(srcdir, fname)
+        text = open(path).read()
+        if text.count(search) != 1:
+            raise SystemExit("apply_ablation %s: the text to replace occurs %d times in %s (the product source moved on: "
+                             "update tools/probes/apply_ablation.py)" % (name, text.count(search), fname))
+        open(path, "w").write(text.replace(search, replace))
+    print("applied ablation %s: %s" % (name, desc))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 2 and sys.argv[1] == "list":
+        for k, (d, _) in ABLATIONS.items():
+            print("%-14s %s" % (k, d))
+    elif len(sys.argv) == 3 and sys.argv[1] in ABLATIONS:
+        apply(sys.argv[1], sys.argv[2])
+    else:
+        raise SystemExit(__doc__)

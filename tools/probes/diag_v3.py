@@ -1,4 +1,4 @@
-"""Where and how the value output of k_trunk_h3<32, 8, 1, 4> goes wrong (tools/probes/heads_batch4_variants.sh): 2x32 network
+"""Where and how the value output of k_trunk_h3<32, 8, 1, 4> goes wrong (the eight round-4 builds; their build script is in the history at 274f240): 2x32 network
 on 8x8, 4096 positions (two workgroups per CU), six launches; per launch the number of positions whose v differs from
 launch 0 / from torch fp32, and over all launches: which wave of the workgroup (position % 4), which workgroup
 (first 256 = first on their CU), the size and sign of the error, and whether a wrong value repeats."""

@@ -1,7 +1,7 @@
 // v_pk_fma_f32 with the HIGH dword of a source pair selected for the LOW lane (`op_sel:[0,1,0]`): is it reliable when two
 // waves share a SIMD?  (Round 4: the value-head FC1 of k_trunk_h3<32, 8, 1, 4> gave wrong values at ~1-2 % of the positions,
 // different ones on every launch, only with two workgroups per CU; builds that differ in NOTHING but this operand form --
-// tools/probes/heads_batch4_variants.sh, variants 6 / 7 / 8 -- are clean with `op_sel_hi:[1,0,1]` (low dword broadcast) and
+// profiles/r04_heads_batch4_variants.txt, variants 6 / 7 / 8 -- are clean with `op_sel_hi:[1,0,1]` (low dword broadcast) and
 // with no operand select, and wrong with `op_sel:[0,1,0]`.)
 //
 // Each wave runs the FC1 shape stand-alone: per batch 32 weight dwords from an L2-resident table and 8 x values from LDS, then
