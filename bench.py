@@ -234,7 +234,16 @@ class Workload:
 
     def play(self, target):
         """One step's self-play: until >= target more games of this rank have finished -> (games, device tuple parts)."""
-        res = self.all_lanes(lambda e, k: e.stream_step(target // self.lanes))
+        # A launch of an fp16-split trunk that clamped an activation is never left standing (the reference's fp32 forward
+        # has no clamp): every lane snapshots its stream before the step, and if the shared evaluator reports a clamp once
+        # all lanes have joined it halves its activation scale and the step is replayed from the snapshots.  Seeded-random
+        # weights (this benchmark) never saturate: the cost is a few MB of device copies per step and lane.
+        while True:
+            rescue = self.ev.precision != "f32"
+            res = self.all_lanes(lambda e, k: ((e.snapshot() if rescue else None), e.stream_step(target // self.lanes))[1])
+            if not (rescue and self.ev.needs_rescue()):
+                break
+            self.all_lanes(lambda e, k: e.restore())
         return sum(r[0] for r in res), [e_.selfplay_device_tensors() for e_ in self.engs]
 
     def counters(self):

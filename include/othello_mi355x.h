@@ -129,18 +129,28 @@ int oth_net_forward_bits(oth_net *net, const uint64_t *self_b, const uint64_t *o
                          int64_t n, const int32_t *n_valid, float *logp, float *v, void *stream);
 /* forward(x) for x float32 [n,3,S,S] holding 0/1 planes (the reference's input format) DEVICE */
 int oth_net_forward_planes(oth_net *net, const float *x, int64_t n, float *logp, float *v, void *stream);
-/* The fp16-split trunk kernels (OTH_PREC_F16X3 / OTH_PREC_F16) clamp activations: the direct kernels (k_trunk16,
- * k_trunk_h3) at 3750 (the f16 range of the hi parts after the 2^4 pre-scale), the Winograd trunks (k_trunk_w, k_trunk_w6:
- * the DEFAULT for 128 filters on 8x8 and 64 filters on 6x6) at 1875 (their transformed operand is up to twice an
- * activation); the reference's fp32 forward (net.py:182-205) does not.  *flag = 1 when any launch
- * since the last call clamped a value -- the results then differ from the reference: reload the weights with
- * OTH_PREC_F32.  Reads and clears a device flag; synchronises `stream`.  HOST flag. */
+/* The fp16-split trunk kernels (OTH_PREC_F16X3 / OTH_PREC_F16) carry activations pre-scaled by a power of two (the
+ * "activation scale", 16 by default: it keeps the low parts of the operand split clear of the f16 subnormals) and clamp the
+ * scaled value at the f16 range: the direct kernels (k_trunk16, k_trunk_h3) at 60000 / scale = 3750, the Winograd trunks
+ * (k_trunk_w, k_trunk_w6: the DEFAULT for 128 filters on 8x8 and 64 filters on 6x6) at 30000 / scale = 1875 (their
+ * transformed operand is up to twice an activation); the reference's fp32 forward (net.py:182-205) has no clamp.
+ * *flag = 1 when any launch since the last call clamped a value -- the results of those launches differ from the
+ * reference's.  The rescue: halve the scale (oth_net_set_act_scale: 16 -> 8 -> ... -> 1 widens the range to 30 000 /
+ * 60 000) and run the affected call again from its start state (oth_engine_snapshot / oth_engine_restore for a stream
+ * step or a lock-step search; a batch run restarts from its seed); only a network that still clamps at scale 1 needs
+ * OTH_PREC_F32.  The Python workers do exactly that.  Reads and clears a device flag; synchronises `stream`.  HOST flag. */
 int oth_net_saturated(oth_net *net, int32_t *flag, void *stream);
+/* The activation scale of the fp16-split trunks (no reference counterpart: net.py:182-205 is fp32 throughout): 1, 2, 4, 8
+ * or 16 (default).  A run-time value -- it enters a launch through the stem's input planes, the biases and the heads'
+ * un-scaling -- that survives oth_net_load_state.  set waits for the device to idle (hipDeviceSynchronize) and rewrites the
+ * scaled biases: call it between calls, never while a launch on this network is in flight.  No effect on OTH_PREC_F32. */
+int oth_net_set_act_scale(oth_net *net, float scale);
+int oth_net_get_act_scale(const oth_net *net, float *scale /*HOST*/);
 /* Which trunk kernel a launch of n positions of this network runs (no reference counterpart: the reference's forward,
  * net.py:182-205, is torch ops; measurement needs the kernel's name and its arithmetic factor from the library, not
  * re-derived by the caller): `name` (HOST, name_cap bytes, NUL-terminated), *issued_per_flop = MFMA FLOPs the kernel
  * issues per algorithmic FLOP of the direct 3x3 convolutions (1.0 exact fp32; 2.75 k_trunk16; 2.0 the Winograd trunks;
- * 3.0 x tile padding k_trunk_h3), *clamp = the activation clamp reported by oth_net_saturated (0 = none).  Any output
+ * 3.0 x tile padding k_trunk_h3), *clamp = the activation clamp at the CURRENT activation scale (0 = none).  Any output
  * pointer may be NULL.  Needs loaded weights; no device work. */
 int oth_net_kernel_info(const oth_net *net, int64_t n, char *name, int32_t name_cap, double *issued_per_flop,
                         double *clamp);
@@ -254,6 +264,16 @@ int oth_selfplay_fetch(oth_engine *e, float *states, float *pis, float *zs, int3
 /* DEVICE pointers to the same compacted arrays (valid until the next run), for on-device consumers
  * such as the RCCL all-gather: no copy. */
 int oth_selfplay_device_ptrs(oth_engine *e, float **states, float **pis, float **zs, int64_t *n_samples);
+
+/* Snapshot / restore of a stream or a lock-step run BETWEEN two calls (no reference counterpart: the reference's fp32
+ * network cannot saturate, parallel_self_play.py:53-78): snapshot copies the slots' game positions, the queued roots, the
+ * status words, the counters and the bookkeeping of the history ring (a few MB, on `stream`) so that a step / search whose
+ * network launches saturated (oth_net_saturated) can be played again from exactly the state it started in after
+ * oth_net_set_act_scale: restore puts that state back, forgets the games the abandoned call finished (their ring
+ * entries are free again) and clears the evaluation cache.  Games are keyed by (seed, game id, ply), so the repeated call
+ * replays the same games.  snapshot: call when no step / search is in progress; restore: needs a snapshot. */
+int oth_engine_snapshot(oth_engine *e, void *stream);
+int oth_engine_restore(oth_engine *e, void *stream);
 
 /* counters of the last run: [0] network evaluations, [1] simulations, [2] plies, [3] games,
  * [4] network batches launched, [5] terminal-leaf simulations, [6] evaluation-cache hits */

@@ -77,6 +77,8 @@ _SIGS = {
     "oth_net_forward_planes": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
     "oth_net_saturated": (C.c_int, [vp, i32p, vp]),
     "oth_net_kernel_info": (C.c_int, [vp, C.c_int64, C.c_char_p, C.c_int32, f64p, f64p]),
+    "oth_net_set_act_scale": (C.c_int, [vp, C.c_float]),
+    "oth_net_get_act_scale": (C.c_int, [vp, f32p]),
     "oth_policy_exp": (C.c_int, [vp, vp, C.c_int64, vp]),
     "oth_engine_create": (vp, [C.POINTER(EngineCfg)]),
     "oth_engine_destroy": (None, [vp]),
@@ -97,6 +99,8 @@ _SIGS = {
     "oth_selfplay_game_ids": (C.c_int, [vp, i32p, C.c_int32, i32p]),
     "oth_selfplay_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "oth_selfplay_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]),
+    "oth_engine_snapshot": (C.c_int, [vp, vp]),
+    "oth_engine_restore": (C.c_int, [vp, vp]),
     "oth_engine_counters": (C.c_int, [vp, i64p]),
     "oth_engine_kernel_time": (C.c_int, [vp, f64p, i64p, f64p, i64p]),
     "oth_engine_set_timing": (C.c_int, [vp, C.c_int32]),

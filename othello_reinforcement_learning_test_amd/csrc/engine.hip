@@ -675,6 +675,7 @@ struct oth_engine {
     oth_net* net = nullptr;
     Dev d{};
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;   // parallel to allocs (oth_engine_snapshot copies some of them)
     int32_t* n_eval2 = nullptr;   // the two evaluation-batch cursors
     int ev_par = 0;               // cursor the NEXT tree launch fills
     // history ring + per-harvest buffers
@@ -707,6 +708,16 @@ struct oth_engine {
     std::vector<double> net_spans;  // (start, end) ms of every network launch of the last run, on the device's reference-event axis
     double net_ms = 0, tree_ms = 0;
     int64_t net_launches = 0, tree_launches = 0;
+    // oth_engine_snapshot / oth_engine_restore: device copies of the small per-slot / bookkeeping arrays + the host fields
+    struct Snap {
+        bool valid = false;
+        std::vector<std::pair<void*, size_t>> regions;   // (source, bytes), fixed at the first snapshot of a ring size
+        std::vector<void*> copies;
+        int32_t hist_cap = 0;
+        int ev_par = 0, round = 0, harvested = 0, cepoch = 0, n_roots = 0;
+        bool lockstep = false, streaming = false;
+        int64_t counters[8] = {0};
+    } snap;
     // result scratch (allocated once): pi/prior f32 [G,65], visits i32 [G,65], value sums f64 [G,65], actions i32 [G]
     float *r_pi = nullptr, *r_prior = nullptr;
     int32_t *r_visits = nullptr, *r_act = nullptr;
@@ -733,6 +744,7 @@ static int dev_alloc(oth_engine* e, T** p, size_t count) {
     OTH_HIP(hipMalloc(&q, count * sizeof(T)));
     OTH_HIP(hipMemset(q, 0, count * sizeof(T)));
     e->allocs.push_back(q);
+    e->alloc_bytes.push_back(count * sizeof(T));
     *p = (T*)q;
     return OTH_OK;
 }
@@ -1114,6 +1126,7 @@ void oth_engine_destroy(oth_engine* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : e->hist_allocs) if (p) (void)hipFree(p);
     if (e->out_states) { (void)hipFree(e->out_states); (void)hipFree(e->out_pis); (void)hipFree(e->out_zs); }
+    for (void* p : e->snap.copies) if (p) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto ev : e->poll_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -1403,6 +1416,70 @@ int oth_stream_step(oth_engine* e, int32_t min_games, int32_t* n_games, int64_t*
     e->harvested = done;
     if (n_games) *n_games = n;
     return harvest(e, n, ids.data(), n_samples, s);
+}
+
+// ---- snapshot / restore (the rescue of a saturated fp16-split launch: see oth_net_saturated in the header) --------------
+// At a call boundary every playing slot is in the state begin_root left it in: an empty tree (n_nodes = n_edges = 0), its
+// root queued (leaf_*, eval_slot, pend = PEND_ROOT, the dense evaluation batch and its cursor) or taken from the evaluation
+// cache (cres).  So the node / edge / path arenas need no copy -- the per-slot words, the batch, the status words, the
+// counters and the ring's bookkeeping do (hist_bits / hist_pi are append-only per (game, ply): a replayed ply rewrites
+// its own entry).
+int oth_engine_snapshot(oth_engine* e, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && (e->streaming || e->lockstep), "oth_engine_snapshot: no stream or lock-step run in progress");
+    OTH_BIND(e->device);
+    hipStream_t s = as_stream(stream);
+    auto& sn = e->snap;
+    if (sn.regions.empty() || sn.hist_cap != e->hist_cap) {
+        for (void* p : sn.copies) if (p) (void)hipFree(p);
+        sn.copies.clear();
+        sn.regions.clear();
+        const Dev& d = e->d;
+        const void* skip[] = {d.nodes, d.edges, d.path, d.ck, d.cv, d.clk, d.sqrt_tab, e->r_pi, e->r_prior, e->r_visits,
+                              e->r_wsum, e->r_act, e->d_total};
+        for (size_t i = 0; i < e->allocs.size(); ++i) {
+            bool sk = false;
+            for (const void* q : skip) sk = sk || q == e->allocs[i];
+            if (!sk) sn.regions.push_back({e->allocs[i], e->alloc_bytes[i]});
+        }
+        const size_t hb = sizeof(int32_t) * (size_t)e->hist_cap;
+        sn.regions.push_back({d.game_len, hb});
+        sn.regions.push_back({d.game_winner, hb});
+        sn.regions.push_back({d.done_list, hb});
+        for (auto& r : sn.regions) {
+            void* c = nullptr;
+            OTH_HIP(hipMalloc(&c, r.second));
+            sn.copies.push_back(c);
+        }
+        sn.hist_cap = e->hist_cap;
+    }
+    for (size_t i = 0; i < sn.regions.size(); ++i)
+        OTH_HIP(hipMemcpyAsync(sn.copies[i], sn.regions[i].first, sn.regions[i].second, hipMemcpyDeviceToDevice, s));
+    sn.ev_par = e->ev_par; sn.round = e->round; sn.harvested = e->harvested; sn.cepoch = e->d.cepoch;
+    sn.n_roots = e->n_roots; sn.lockstep = e->lockstep; sn.streaming = e->streaming;
+    memcpy(sn.counters, e->counters, sizeof(sn.counters));
+    sn.valid = true;
+    return OTH_OK;
+}
+
+int oth_engine_restore(oth_engine* e, void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && e->snap.valid && e->snap.hist_cap == e->hist_cap, "oth_engine_restore: no snapshot of this run");
+    OTH_BIND(e->device);
+    hipStream_t s = as_stream(stream);
+    auto& sn = e->snap;
+    OTH_HIP(hipStreamSynchronize(s));   // the abandoned call has ended (its last poll / harvest synchronised); be sure
+    for (size_t i = 0; i < sn.regions.size(); ++i)
+        OTH_HIP(hipMemcpyAsync(sn.regions[i].first, sn.copies[i], sn.regions[i].second, hipMemcpyDeviceToDevice, s));
+    e->ev_par = sn.ev_par; e->round = sn.round; e->d.round = sn.round; e->harvested = sn.harvested;
+    e->n_roots = sn.n_roots; e->lockstep = sn.lockstep; e->streaming = sn.streaming;
+    memcpy(e->counters, sn.counters, sizeof(sn.counters));
+    int r = cache_clear(e, s);   // entries inserted by the abandoned call hold clamped outputs
+    if (r) return r;
+    e->d.cepoch = 0;
+    spans_reset(e);
+    OTH_HIP(hipStreamSynchronize(s));
+    return OTH_OK;
 }
 
 int oth_selfplay_game_ids(oth_engine* e, int32_t* ids, int32_t capacity, int32_t* count) {

@@ -57,6 +57,14 @@ struct oth_net {
     oth::HostNet host;
     float* d_heads = nullptr;  // one allocation: the fp32 head parameters (shared by both trunk kernels)
     int* d_sat = nullptr;      // device flag: an fp16-split trunk kernel clamped an activation (oth_net_saturated)
+    // Activations of the fp16-split trunks are carried PRE-SCALED by act_scale (a power of two, 16 by default: it keeps the
+    // lo parts of the operand split clear of the f16 subnormals) and clamped at the f16 range of that scaled value; the
+    // reference's fp32 forward has no clamp.  The scale enters a launch through the stem's input planes, the biases
+    // (dev = host x act_scale: the arrays registered below) and the heads' un-scaling, so it is a RUN-TIME value:
+    // oth_net_set_act_scale halves it when a launch saturated (range 1875 -> 30 000 at scale 1 in the Winograd trunks).
+    float act_scale = 16.0f;
+    struct ScaledBias { float* dev; std::vector<float> host; };
+    std::vector<ScaledBias> scaled_bias;
     oth::HeadParams heads{};
     // exact-fp32 MFMA path (any filter count, 8x8 and 6x6): net_f32.hip
     oth::F32Weights* f32 = nullptr;
@@ -82,6 +90,8 @@ struct oth_net {
     } while (0)
 
 namespace oth {
+// upload host x net->act_scale to dev and keep both for oth_net_set_act_scale (dev stays owned by the caller's weight struct)
+int register_scaled_bias(oth_net* net, float* dev, std::vector<float> host);   // net.hip
 int mfma_pack_weights(oth_net* net, int precision);  // net_mfma.hip
 void mfma_free_weights(oth_net* net);
 int mfma_forward(oth_net* net, const uint64_t* self_b, const uint64_t* opp_b, const uint64_t* legal, int64_t n,

@@ -77,11 +77,20 @@ __global__ void k_planes_to_bits(const float* __restrict__ x, uint64_t* __restri
     }
 }
 
+int register_scaled_bias(oth_net* net, float* dev, std::vector<float> host) {
+    std::vector<float> up(host.size());
+    for (size_t i = 0; i < host.size(); ++i) up[i] = host[i] * net->act_scale;
+    OTH_HIP(hipMemcpy(dev, up.data(), up.size() * sizeof(float), hipMemcpyHostToDevice));
+    net->scaled_bias.push_back({dev, std::move(host)});
+    return OTH_OK;
+}
+
 }  // namespace oth
 
 using namespace oth;
 
 static void net_free_device(oth_net* net) {
+    net->scaled_bias.clear();   // (the device arrays belong to the weight structs freed below)
     if (net->d_heads) (void)hipFree(net->d_heads);
     net->d_heads = nullptr;
     if (net->d_sat) (void)hipFree(net->d_sat);
@@ -150,24 +159,24 @@ int oth_net_kernel_info(const oth_net* net, int64_t n, char* name, int32_t name_
     } else if (net->wino6) {
         k = "k_trunk_w6 (fused ResNet forward, 6x6, 1-D Winograd F(2,3) residual convolutions, eight positions per workgroup)";
         issued = 3.0 * 2.0 / 3.0;   // three split products, 4 multiplies per 2 outputs instead of 6, every N-tile full
-        cl = 1875.0;
+        cl = 30000.0 / net->act_scale;   // 1875 at the default scale 16
     } else if (net->h3) {
         k = "k_trunk_h3 (fused ResNet forward, direct 3x3, one wave per position group)";
         // three split products; N-tiles of 16 cells over the wave's positions (P = 2 on 6x6 with 64 filters, 4 with 32, else 1)
         const int cells = net->board * net->board;
         const int P = net->board == 6 ? (net->filters == 64 ? 2 : net->filters == 32 ? 4 : 1) : 1;
         issued = 3.0 * (double)((P * cells + 15) / 16 * 16) / (double)(P * cells);
-        cl = 3750.0;
+        cl = 60000.0 / net->act_scale;   // 3750 at the default scale 16
     } else if (net->wino) {
         k = wino_positions_per_workgroup(n) == 2 ? "k_trunk_w<2> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, two positions per workgroup)"
                     : "k_trunk_w<1> (fused ResNet forward, 1-D Winograd F(2,3) residual convolutions, one position per workgroup)";
         issued = 3.0 * 2.0 / 3.0;
-        cl = 1875.0;
+        cl = 30000.0 / net->act_scale;   // 1875 at the default scale 16
     } else {
         const bool x3 = net->precision != OTH_PREC_F16;
         k = x3 ? "k_trunk16 (fused ResNet forward, direct 3x3, fp16 hi/lo split)" : "k_trunk16 (fused ResNet forward, direct 3x3, single fp16 pass)";
         issued = (x3 ? 3.0 : 1.0) * 11.0 / 12.0;   // the all-padding row tiles of the dy = -1 / +1 taps are skipped
-        cl = 3750.0;
+        cl = 60000.0 / net->act_scale;   // 3750 at the default scale 16
     }
     if (name && name_cap > 0) {
         strncpy(name, k, (size_t)name_cap - 1);
@@ -175,6 +184,32 @@ int oth_net_kernel_info(const oth_net* net, int64_t n, char* name, int32_t name_
     }
     if (issued_per_flop) *issued_per_flop = issued;
     if (clamp) *clamp = cl;
+    return OTH_OK;
+}
+
+int oth_net_get_act_scale(const oth_net* net, float* scale) {
+    OTH_CHECK(net && scale, "oth_net_get_act_scale: null argument");
+    *scale = net->act_scale;
+    return OTH_OK;
+}
+
+int oth_net_set_act_scale(oth_net* net, float scale) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(net, "oth_net_set_act_scale: null network");
+    OTH_CHECK(scale == 1.f || scale == 2.f || scale == 4.f || scale == 8.f || scale == 16.f,
+              "oth_net_set_act_scale: the scale must be 1, 2, 4, 8 or 16 (got %g)", (double)scale);
+    OTH_BIND(net->device);
+    if (scale == net->act_scale) return OTH_OK;
+    // the biases of the fp16-split trunks are stored x act_scale: no launch on this network may be in flight while they
+    // are rewritten (callers change the scale between calls; this makes sure)
+    OTH_HIP(hipDeviceSynchronize());
+    net->act_scale = scale;
+    std::vector<float> up;
+    for (auto& sbias : net->scaled_bias) {
+        up.resize(sbias.host.size());
+        for (size_t i = 0; i < up.size(); ++i) up[i] = sbias.host[i] * scale;
+        OTH_HIP(hipMemcpy(sbias.dev, up.data(), up.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return OTH_OK;
 }
 

@@ -38,11 +38,10 @@ using half8 = _Float16 __attribute__((ext_vector_type(8)));
 using half4 = _Float16 __attribute__((ext_vector_type(4)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-constexpr float kH3ActScale = 16.0f;  // 2^4
 
 struct H3Weights {
     uint4* d_w = nullptr;        // [layer][tap][k-step][row block][hi, lo][64 lanes] x 16 B
-    float* d_bias = nullptr;     // [layers][F], pre-multiplied by kH3ActScale
+    float* d_bias = nullptr;     // [layers][F], x act_scale (register_scaled_bias)
     float* d_inv = nullptr;      // [layers] 1 / weight scale
     float* d_pfc_wt = nullptr;   // transposed head FCs (net_heads_wave.h)
     float* d_vfc1_wt = nullptr;
@@ -59,6 +58,7 @@ struct H3Args {
     const float* pfc_wt;
     const float* vfc1_wt;
     int* sat;   // set to 1 when an activation reaches the clamp (oth_net_saturated)
+    float act_scale;   // oth_net::act_scale: the stem's input value and the heads' un-scaling
     unsigned long long* dbg;   // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
 
@@ -164,9 +164,9 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
         if (pos0 + p < nv && lane < CELLS) {
             const uint64_t b0 = sb[pos0 + p], b1 = ob[pos0 + p], b2 = lgl[pos0 + p];
             half4 v;
-            v[0] = (b0 >> lane) & 1ULL ? (_Float16)kH3ActScale : (_Float16)0.0f;
-            v[1] = (b1 >> lane) & 1ULL ? (_Float16)kH3ActScale : (_Float16)0.0f;
-            v[2] = (b2 >> lane) & 1ULL ? (_Float16)kH3ActScale : (_Float16)0.0f;
+            v[0] = (b0 >> lane) & 1ULL ? (_Float16)a.act_scale : (_Float16)0.0f;
+            v[1] = (b1 >> lane) & 1ULL ? (_Float16)a.act_scale : (_Float16)0.0f;
+            v[2] = (b2 >> lane) & 1ULL ? (_Float16)a.act_scale : (_Float16)0.0f;
             v[3] = (_Float16)0.0f;
             const int idx = 1 + p * POSC + (lane / BS + 1) * BS + (lane % BS);
             *(half4*)(act + (size_t)idx * 16) = v;   // chunk 0, halfs 0..3
@@ -381,10 +381,11 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
     }
 #undef OTH_SB
 
-    // ---- heads: the final activations (in `res`, scaled by 2^4) as fp32 planes [channel][output cell], aliasing
+    // ---- heads: the final activations (in `res`, x act_scale) as fp32 planes [channel][output cell], aliasing
     //      the activation arrays (every read of them is done)
     if (sat_bits >= __float_as_uint(60000.f)) atomicOr(a.sat, 1);   // rare: surfaced by oth_net_saturated
     float* planes = (float*)act;
+    const float us = 1.0f / a.act_scale;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
             if (valid[t]) {
                 const int ci = t * 16 + n16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) planes[(b * 16 + 4 * g4 + r) * NCO + ci] = res[b][t][r] * (1.0f / kH3ActScale);
+                for (int r = 0; r < 4; ++r) planes[(b * 16 + 4 * g4 + r) * NCO + ci] = res[b][t][r] * us;
             }
     OTH_HSTAMP(3)
     {   // all P positions of the wave at once (shared FC weight loads); dead positions compute on zero planes, unstored
@@ -489,7 +490,7 @@ int h3_pack_weights(oth_net* net) {
         hw->layer_off[l] = (uint32_t)(w.size() / 8);
         const float sc = pack_layer_h3(c, F, l == 0 ? 1 : F / 32, w);
         inv[l] = 1.0f / sc;   // accumulator = (16 x) * (sc w): times 1/sc gives 16 * y
-        for (int i = 0; i < F; ++i) bias[(size_t)l * F + i] = c.bias[i] * kH3ActScale;
+        for (int i = 0; i < F; ++i) bias[(size_t)l * F + i] = c.bias[i];
     }
     std::vector<float> pt((size_t)2 * cells * NP), vt((size_t)cells * 256);
     for (int o = 0; o < NP; ++o)
@@ -502,7 +503,7 @@ int h3_pack_weights(oth_net* net) {
     OTH_HIP(hipMalloc(&hw->d_pfc_wt, pt.size() * 4));
     OTH_HIP(hipMalloc(&hw->d_vfc1_wt, vt.size() * 4));
     OTH_HIP(hipMemcpy(hw->d_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
-    OTH_HIP(hipMemcpy(hw->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = register_scaled_bias(net, hw->d_bias, std::move(bias))) return rc;
     OTH_HIP(hipMemcpy(hw->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(hw->d_pfc_wt, pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(hw->d_vfc1_wt, vt.data(), vt.size() * 4, hipMemcpyHostToDevice));
@@ -567,6 +568,7 @@ int h3_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uint6
     a.pfc_wt = net->h3->d_pfc_wt;
     a.vfc1_wt = net->h3->d_vfc1_wt;
     a.sat = net->d_sat;
+    a.act_scale = net->act_scale;
     const int F = net->filters;
 #define OTH_H3_CASE(FF, BB, PP, WW, SH) \
     if (F == FF && net->board == BB) return launch_h3<FF, BB, PP, WW, SH>(net, a, sb, ob, lg, n, n_valid, logp, v, stream)

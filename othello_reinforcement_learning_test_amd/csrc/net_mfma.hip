@@ -50,15 +50,15 @@ constexpr int kActBytes = 256 * kCellBytes;    // 131072
 constexpr int kZeroOff = kActBytes;            // zero cell (512 B)
 constexpr int kScratchOff = kActBytes + 512;   // stem im2col (16 KiB) / head scratch
 constexpr int kLdsBytes = kScratchOff + 16384;
-constexpr float kActScale = 16.0f;             // 2^4
-constexpr float kActClamp = 60000.0f;          // activations are clamped to 60000 / 16 = 3750 (the f16 range of the hi parts)
+constexpr float kActClamp = 60000.0f;          // activations x act_scale are clamped to the f16 range of the hi parts: activations
+                                               // <= 60000 / act_scale (3750 at the default scale 16; oth_net::act_scale)
 
 struct MfmaWeights {
     int blocks = 0;
     int shape = 32;            // MFMA shape the fragments are packed for: 32 (32x32x16) or 16 (16x16x32)
     uint4* d_w = nullptr;      // fragments: [layer][step 0..71][wave 0..3][plane hi,lo][64 lanes] x 16 B
     uint4* d_stem = nullptr;   // [step 0..1][wave][plane][64 lanes]
-    float* d_bias = nullptr;   // [1 + 2*blocks][128], pre-multiplied by kActScale
+    float* d_bias = nullptr;   // [1 + 2*blocks][128], x act_scale (register_scaled_bias)
     float* d_inv = nullptr;    // [1 + 2*blocks] 1 / weight_scale
 };
 
@@ -72,6 +72,7 @@ struct MfmaArgs {
     unsigned long long* dbg;  // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
     unsigned long long* tl;   // diagnostic build only: per-layer conv start / end of workgroups 0 and 256
     int* sat;                 // set to 1 when an activation reaches the clamp (oth_net_saturated)
+    float act_scale;          // oth_net::act_scale: the stem's input value and the heads' un-scaling
 };
 
 #ifdef OTH_STAMPS
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
             const int s = ok ? yy * 8 + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
+            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
+            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
+            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
         }
         half8* dst = (half8*)(lds + kScratchOff + tid * 64);
 #pragma unroll
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
         wr_off[g] = (uint32_t)r * kCellBytes + ((((uint32_t)(wave * 4 + g)) ^ keyw) << 4) + 8u * (uint32_t)h;
     const int ch0 = wave * 32 + 4 * h;  // + 8g + e
 
-    // Activations and the residual are carried PRE-SCALED by kActScale (ReLU commutes with a positive
-    // scale): res16 = 16 * x.  bias16/inv16 are prepared on the host.
+    // Activations and the residual are carried PRE-SCALED by a.act_scale (ReLU commutes with a positive
+    // scale): res16 = act_scale * x (16 by default).  bias16/inv16 are prepared on the host.
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
     uint4 wq_h[PB], wq_l[PB];  // weight-fragment ring of the conv that FOLLOWS the current epilogue
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float us = 1.0f / kActScale;
+            const float us = 1.0f / a.act_scale;
             const float4 o = make_float4(res[t][4 * g] * us, res[t][4 * g + 1] * us, res[t][4 * g + 2] * us,
                                          res[t][4 * g + 3] * us);
             *(float4*)(lds + (size_t)(t * 32 + r) * 512 + (size_t)(ch0 + 8 * g) * 4) = o;
@@ -432,9 +433,9 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
             const int s = ok ? yy * 8 + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)kActScale : (_Float16)0.0f;
+            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
+            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
+            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
         }
         half8* dst = (half8*)(lds + SCR_OFF + tid * 64);
 #pragma unroll
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256, (TP == 2 ? 2 : 1)) void k_trunk16(MfmaArgs a, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const float us = 1.0f / kActScale;
+            const float us = 1.0f / a.act_scale;
             const float4 o = make_float4(res[t][rb][0] * us, res[t][rb][1] * us, res[t][rb][2] * us, res[t][rb][3] * us);
             *(float4*)(lds + (size_t)(OTH_TILE_CELL(t) + lane_cell) * 512 + (size_t)(ch0 + 16 * rb) * 4) = o;
         }
@@ -859,13 +860,13 @@ int mfma_pack_weights(oth_net* net, int precision) {
     {
         const float sc = mw->shape == 16 ? pack_conv16(hn.stem, stem, 0, 1, ks) : pack_conv(hn.stem, 32, stem, 0, 2, ks);
         inv[0] = 1.0f / sc;  // accumulator holds (16 x) * (sc w): divide by sc to get 16 * y
-        for (int i = 0; i < 128; ++i) bias[i] = hn.stem.bias[i] * kActScale;
+        for (int i = 0; i < 128; ++i) bias[i] = hn.stem.bias[i];
     }
     for (int l = 0; l < L; ++l) {
         const float sc = mw->shape == 16 ? pack_conv16(hn.res[l], w, (size_t)l * layer_halfs, 36, km)
                                          : pack_conv(hn.res[l], 1152, w, (size_t)l * layer_halfs, 72, km);
         inv[l + 1] = 1.0f / sc;
-        for (int i = 0; i < 128; ++i) bias[(size_t)(l + 1) * 128 + i] = hn.res[l].bias[i] * kActScale;
+        for (int i = 0; i < 128; ++i) bias[(size_t)(l + 1) * 128 + i] = hn.res[l].bias[i];
     }
     OTH_HIP(hipMalloc(&mw->d_w, w.size() * 2));
     OTH_HIP(hipMalloc(&mw->d_stem, stem.size() * 2));
@@ -873,7 +874,7 @@ int mfma_pack_weights(oth_net* net, int precision) {
     OTH_HIP(hipMalloc(&mw->d_inv, inv.size() * 4));
     OTH_HIP(hipMemcpy(mw->d_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(mw->d_stem, stem.data(), stem.size() * 2, hipMemcpyHostToDevice));
-    OTH_HIP(hipMemcpy(mw->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = register_scaled_bias(net, mw->d_bias, std::move(bias))) return rc;
     OTH_HIP(hipMemcpy(mw->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
     return OTH_OK;
 }
@@ -891,6 +892,7 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     a.dbg = nullptr;
     a.tl = nullptr;
     a.sat = net->d_sat;
+    a.act_scale = net->act_scale;
 #ifdef OTH_STAMPS
     OTH_HIP(hipMalloc(&a.tl, 128 * sizeof(unsigned long long)));
     OTH_HIP(hipMemset(a.tl, 0, 128 * sizeof(unsigned long long)));

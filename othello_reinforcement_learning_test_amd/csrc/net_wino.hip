@@ -41,14 +41,14 @@ constexpr int kWTile = 512;                   // bytes of one (position, tile, x
 constexpr int kWVBytes = 2 * 32 * 4 * kWTile; // 131072
 constexpr int kWZeroOff = kWVBytes;           // 4 x 512 B of zeros: the source of out-of-board rows, any xi
 constexpr int kWLds = kWVBytes + 4 * kWTile;  // 133120
-constexpr float kWActScale = 16.0f;           // activations and residual are carried x 2^4 (as in net_mfma.hip)
-constexpr float kWClamp = 30000.0f;           // |V| <= 2 x activation must stay in the f16 range: activations <= 1875
+constexpr float kWClamp = 30000.0f;           // |V| <= 2 x (activation x act_scale) must stay in the f16 range: activations
+                                              // <= 30000 / act_scale (1875 at the default scale 16; oth_net::act_scale)
 
 struct WinoWeights {
     int blocks = 0;
     uint4* d_w = nullptr;     // [layer][dy 3][kk 4][wave 8][xi 4][hi, lo][64 lanes] x 16 B   (A fragments of U)
     uint4* d_stem = nullptr;  // [wave 8][hi, lo][64 lanes] x 16 B: direct 3x3 stem as one k-step of 32 (27 used)
-    float* d_bias = nullptr;  // [1 + 2*blocks][128], x kWActScale
+    float* d_bias = nullptr;  // [1 + 2*blocks][128], x act_scale (register_scaled_bias)
     float* d_inv = nullptr;   // [1 + 2*blocks] 1 / weight scale
     float* d_pfc_wt = nullptr;   // [128][65]  policy FC transposed: lanes read consecutive outputs
     float* d_vfc1_wt = nullptr;  // [64][256]  value FC1 transposed
@@ -64,6 +64,7 @@ struct WinoArgs {
     const float* pfc_wt;
     const float* vfc1_wt;
     int* sat;
+    float act_scale;           // oth_net::act_scale: the stem's input value and the heads' un-scaling
     unsigned long long* dbg;   // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
         const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
         // the rows of odd-x output cells are NEGATED: the stem's result then has the form of a Winograd-domain
         // accumulator set (M0 = y0, M1 = M2 = 0, M3 = -y1) and goes through the same epilogue as every other layer
-        const _Float16 one = (x & 1) ? (_Float16)(-kWActScale) : (_Float16)kWActScale;
+        const _Float16 one = (x & 1) ? (_Float16)(-a.act_scale) : (_Float16)a.act_scale;
         _Float16 vals[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     __syncthreads();
 
     f32x4 acc[4][NT];    // [xi][N-tile]
-    f32x4 res[NT][2];    // [N-tile][x parity]: the residual in the spatial domain, fp32, x 2^4
+    f32x4 res[NT][2];    // [N-tile][x parity]: the residual in the spatial domain, fp32, x act_scale
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     unsigned long long ph_[4] = {0, 0, 0, 0}, t0_ = w_clk(), tstart_ = t0_;
     const unsigned long long rstart_ = w_realclk();
 #endif
-    float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x 2^4) and 1 / weight scale of the layer in the epilogue
+    float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x act_scale) and 1 / weight scale of the layer in the epilogue
     float inv = a.inv[0], invn = inv;
     for (int layer = 0; layer < n_layers; ++layer) {
         const bool last = layer == n_layers - 1;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
     const unsigned long long theads_ = w_clk();
 #endif
 
-    // ---------------- heads (fp32 VALU): final activations (in `res`, x 2^4) -> LDS [128 cells][128] f32, then the
+    // ---------------- heads (fp32 VALU): final activations (in `res`, x act_scale) -> LDS [128 cells][128] f32, then the
     // shared head code (256 of the 512 threads do the per-thread parts; all of them take its barriers)
     if (sat_bits >= __float_as_uint(kWClamp)) atomicOr(a.sat, 1);
     __syncthreads();
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_w(WinoArgs a, const uint64_t* 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int cell = (nt >> 1) * 64 + ((nt & 1) * 4 + row4) * 8 + 2 * j + e;
-            const float us = 1.0f / kWActScale;
+            const float us = 1.0f / a.act_scale;
             const f32x4 v = res[nt][e];
             float* dst = (float*)lds + (size_t)cell * kHeadRow + ch0;   // odd row stride: four scalar stores
             dst[0] = v[0] * us;
@@ -599,7 +600,7 @@ int wino_pack_weights(oth_net* net) {
                     stem[((size_t)wv * 2 + 1) * frag + (size_t)l * 8 + jj] = lo;
                 }
         inv[0] = 1.0f / scale;
-        for (int i = 0; i < 128; ++i) bias[i] = cv.bias[i] * kWActScale;
+        for (int i = 0; i < 128; ++i) bias[i] = cv.bias[i];
     }
     static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
     std::vector<double> U((size_t)3 * 4 * 128 * 128);   // [dy][xi][ci][co]
@@ -633,7 +634,7 @@ int wino_pack_weights(oth_net* net) {
                                 w[f0 + frag + (size_t)l * 8 + jj] = lo;
                             }
         inv[li + 1] = (float)(1.0 / scale);
-        for (int i = 0; i < 128; ++i) bias[(size_t)(li + 1) * 128 + i] = cv.bias[i] * kWActScale;
+        for (int i = 0; i < 128; ++i) bias[(size_t)(li + 1) * 128 + i] = cv.bias[i];
     }
     std::vector<float> pt((size_t)128 * 65), vt((size_t)64 * 256);
     for (int o = 0; o < 65; ++o)
@@ -650,7 +651,7 @@ int wino_pack_weights(oth_net* net) {
     OTH_HIP(hipMalloc(&ww->d_inv, inv.size() * 4));
     OTH_HIP(hipMemcpy(ww->d_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(ww->d_stem, stem.data(), stem.size() * 2, hipMemcpyHostToDevice));
-    OTH_HIP(hipMemcpy(ww->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = register_scaled_bias(net, ww->d_bias, std::move(bias))) return rc;
     OTH_HIP(hipMemcpy(ww->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
     return OTH_OK;
 }
@@ -677,6 +678,7 @@ int wino_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     a.pfc_wt = net->wino->d_pfc_wt;
     a.vfc1_wt = net->wino->d_vfc1_wt;
     a.sat = net->d_sat;
+    a.act_scale = net->act_scale;
     a.dbg = nullptr;
 #ifdef OTH_STAMPS
     const unsigned dbg_grid = (unsigned)n;

@@ -45,8 +45,8 @@ constexpr int k6ZeroOff = k6VBytes;             // a plane of zeros: the source 
 constexpr int k6Lds = k6VBytes + k6PlaneBytes;  // 159744 of the CU's 163840
 // byte offset of the run (j, xi, k-step, half) inside a plane
 __host__ __device__ constexpr int k6_run(int j, int xi, int kk, int half) { return (((j * 4 + xi) * 2 + kk) * 2 + half) * k6RunBytes; }
-constexpr float k6ActScale = 16.0f;             // activations and residual are carried x 2^4
-constexpr float k6Clamp = 30000.0f;             // |V| <= 2 x activation must stay in the f16 range: activations <= 1875
+constexpr float k6Clamp = 30000.0f;             // |V| <= 2 x (activation x act_scale) must stay in the f16 range: activations
+                                                // <= 30000 / act_scale (1875 at the default 16; oth_net::act_scale)
 constexpr int k6Groups = 6;                     // (row tap d, k-step kk of 32 input channels): g = 2*d + kk
 constexpr int k6GroupU4 = 4 * 8 * 64;           // uint4 per group: 4 waves x 8 fragments x 64 lanes
 
@@ -54,7 +54,7 @@ struct Wino6Weights {
     int blocks = 0;
     uint4* d_w = nullptr;     // [layer][group 6][wave 4][xi 4][hi, lo][64 lanes] x 16 B   (A fragments of U)
     uint4* d_stem = nullptr;  // [wave 4][hi, lo][64 lanes] x 16 B: direct 3x3 stem as one k-step of 32 (27 used)
-    float* d_bias = nullptr;  // [1 + 2*blocks][64], x k6ActScale
+    float* d_bias = nullptr;  // [1 + 2*blocks][64], x act_scale (register_scaled_bias)
     float* d_inv = nullptr;   // [1 + 2*blocks] 1 / weight scale
     float* d_pfc_wt = nullptr;   // [72][37]  policy FC transposed (net_heads_wave.h)
     float* d_vfc1_wt = nullptr;  // [36][256] value FC1 transposed
@@ -70,6 +70,7 @@ struct Wino6Args {
     const float* pfc_wt;
     const float* vfc1_wt;
     int* sat;
+    float act_scale;           // oth_net::act_scale: the stem's input value and the heads' un-scaling
     unsigned long long* dbg;   // diagnostic build (-DOTH_STAMPS) only: per-wave phase cycle sums
 };
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
         const int p = ci / k6Cells, cell = ci % k6Cells, y = cell / k6BS, x = cell % k6BS;
         const bool live = pos0 + p < nv;
         const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
-        const _Float16 one = (x & 1) ? (_Float16)(-k6ActScale) : (_Float16)k6ActScale;
+        const _Float16 one = (x & 1) ? (_Float16)(-a.act_scale) : (_Float16)a.act_scale;
         _Float16 vals[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
     __syncthreads();
 
     f32x4 acc[4][k6NT];   // [xi][N-tile]
-    f32x4 res[k6NT][2];   // [N-tile][x parity]: the residual in the spatial domain, fp32, x 2^4
+    f32x4 res[k6NT][2];   // [N-tile][x parity]: the residual in the spatial domain, fp32, x act_scale
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
     uint32_t sat_bits = 0;
     OTH_W6STAMP(0)
     u32x4 wq[2][8];   // weight ring: [group parity][xi hi, xi lo]; a group = (row tap, k-step): 8 fragments
-    float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x 2^4) and 1 / weight scale of the layer in the epilogue
+    float4 b4 = *(const float4*)(a.bias + ch0), b4n = b4;   // bias (x act_scale) and 1 / weight scale of the layer in the epilogue
     float inv = a.inv[0], invn = inv;
     for (int layer = 0; layer < n_layers; ++layer) {
         const bool last = layer == n_layers - 1;
@@ -376,13 +377,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
         conv_d(std::integral_constant<int, 2>{});
     }
 
-    // ---------------- heads (fp32 VALU): final activations (in `res`, x 2^4) -> LDS planes [channel][8 x 36 cells] f32
+    // ---------------- heads (fp32 VALU): final activations (in `res`, x act_scale) -> LDS planes [channel][8 x 36 cells] f32
     //                  (aliasing V: every read of it is done), then each wave runs the shared one-wave head code on two
     //                  of the eight positions
     if (sat_bits >= __float_as_uint(k6Clamp)) atomicOr(a.sat, 1);
     __syncthreads();
     constexpr int NCO = k6TP * k6Cells;   // 288
     float* planes = (float*)lds;
+    const float us = 1.0f / a.act_scale;
 #pragma unroll
     for (int lg = 0; lg < 3; ++lg)
 #pragma unroll
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
                 const int ci = p_l[lg] * k6Cells + row_l[lg] * k6BS + 2 * j + e;
                 const f32x4 v = res[lg * 3 + j][e];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) planes[(ch0 + r) * NCO + ci] = v[r] * (1.0f / k6ActScale);
+                for (int r = 0; r < 4; ++r) planes[(ch0 + r) * NCO + ci] = v[r] * us;
             }
     __syncthreads();
     {
@@ -475,7 +477,7 @@ int wino6_pack_weights(oth_net* net) {
                     stem[((size_t)wv * 2 + 1) * frag + (size_t)l * 8 + jj] = lo;
                 }
         inv[0] = 1.0f / scale;
-        for (int i = 0; i < k6F; ++i) bias[i] = cv.bias[i] * k6ActScale;
+        for (int i = 0; i < k6F; ++i) bias[i] = cv.bias[i];
     }
     static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
     std::vector<double> U((size_t)3 * 4 * k6F * k6F);   // [dy][xi][ci][co]
@@ -509,7 +511,7 @@ int wino6_pack_weights(oth_net* net) {
                                 w[f0 + frag + (size_t)l * 8 + jj] = lo;
                             }
         inv[li + 1] = (float)(1.0 / scale);
-        for (int i = 0; i < k6F; ++i) bias[(size_t)(li + 1) * k6F + i] = cv.bias[i] * k6ActScale;
+        for (int i = 0; i < k6F; ++i) bias[(size_t)(li + 1) * k6F + i] = cv.bias[i];
     }
     std::vector<float> pt((size_t)2 * k6Cells * k6NP), vt((size_t)k6Cells * 256);
     for (int o = 0; o < k6NP; ++o)
@@ -526,7 +528,7 @@ int wino6_pack_weights(oth_net* net) {
     OTH_HIP(hipMemcpy(ww->d_vfc1_wt, vt.data(), vt.size() * 4, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(ww->d_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
     OTH_HIP(hipMemcpy(ww->d_stem, stem.data(), stem.size() * 2, hipMemcpyHostToDevice));
-    OTH_HIP(hipMemcpy(ww->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = register_scaled_bias(net, ww->d_bias, std::move(bias))) return rc;
     OTH_HIP(hipMemcpy(ww->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
     return OTH_OK;
 }
@@ -545,6 +547,7 @@ int wino6_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const ui
     a.pfc_wt = net->wino6->d_pfc_wt;
     a.vfc1_wt = net->wino6->d_vfc1_wt;
     a.sat = net->d_sat;
+    a.act_scale = net->act_scale;
     static bool attr_set_dev[64] = {};
     bool& attr_set = attr_set_dev[net->device & 63];
     if (!attr_set) {

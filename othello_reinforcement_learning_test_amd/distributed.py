@@ -138,7 +138,7 @@ class DistributedSelfPlayWorker:
         self._calls += 1
         import torch
         if mine > 0:
-            eng.selfplay_run(mine, seed, add_dirichlet_noise)
+            eng.selfplay_run_rescued(mine, seed, add_dirichlet_noise)   # (restarted from its seed if a launch saturated)
             st, pi, z = eng.selfplay_device_tensors()
         else:
             st = torch.empty((0, 3, eng.board_size, eng.board_size), dtype=torch.float32, device="cuda")   # 6x6: (0,3,6,6)

@@ -42,6 +42,8 @@ class HipResNetEvaluator:
         if not self._h:
             raise _lib.OthelloHipError("oth_net_create: " + _lib.last_error())
         self._version = None
+        # rescue of a saturated launch (see needs_rescue): how often it happened, and what was done about it
+        self.rescues = []
         self.refresh()
 
     def _model_version(self):
@@ -63,8 +65,12 @@ class HipResNetEvaluator:
     def handle(self):
         return self._h
 
-    def forward_planes(self, x):
-        """x: CUDA float32 (N,3,S,S) of 0/1 planes -> (log-probs (N,S*S+1), value (N,1)) CUDA tensors."""
+    def forward_planes(self, x, rescue=True):
+        """x: CUDA float32 (N,3,S,S) of 0/1 planes -> (log-probs (N,S*S+1), value (N,1)) CUDA tensors.
+
+        ``rescue=True`` (default): an fp16-split launch that clamped an activation is run again at a lower activation
+        scale (``needs_rescue``; the check synchronises the stream).  ``rescue=False`` launches once, asynchronously,
+        and leaves the device flag for the caller (``saturated`` / ``check_saturation``)."""
         import torch
         x = x.contiguous()
         n = x.shape[0]
@@ -72,19 +78,23 @@ class HipResNetEvaluator:
             raise ValueError("expected input of shape (N,3,%d,%d)" % (self.board_size, self.board_size))
         logp = torch.empty((n, self.policy_size), dtype=torch.float32, device=x.device)
         v = torch.empty((n,), dtype=torch.float32, device=x.device)
-        _lib.call("oth_net_forward_planes", self._h, x.data_ptr(), n, logp.data_ptr(), v.data_ptr(),
-                  _lib.current_stream())
-        return logp, v.view(n, 1)
+        while True:
+            _lib.call("oth_net_forward_planes", self._h, x.data_ptr(), n, logp.data_ptr(), v.data_ptr(),
+                      _lib.current_stream())
+            if not (rescue and self.needs_rescue()):
+                return logp, v.view(n, 1)
 
-    def forward_bits(self, self_b, opp_b, legal):
-        """Packed-bitboard input (CUDA int64 tensors) -> (log-probs, value)."""
+    def forward_bits(self, self_b, opp_b, legal, rescue=True):
+        """Packed-bitboard input (CUDA int64 tensors) -> (log-probs, value); ``rescue`` as in forward_planes."""
         import torch
         n = self_b.numel()
         logp = torch.empty((n, self.policy_size), dtype=torch.float32, device=self_b.device)
         v = torch.empty((n,), dtype=torch.float32, device=self_b.device)
-        _lib.call("oth_net_forward_bits", self._h, self_b.data_ptr(), opp_b.data_ptr(), legal.data_ptr(),
-                  n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
-        return logp, v.view(n, 1)
+        while True:
+            _lib.call("oth_net_forward_bits", self._h, self_b.data_ptr(), opp_b.data_ptr(), legal.data_ptr(),
+                      n, None, logp.data_ptr(), v.data_ptr(), _lib.current_stream())
+            if not (rescue and self.needs_rescue()):
+                return logp, v.view(n, 1)
 
     def kernel_info(self, n_positions=4096):
         """Which trunk kernel a launch of ``n_positions`` runs, as the library itself dispatches it:
@@ -92,25 +102,64 @@ class HipResNetEvaluator:
         name = C.create_string_buffer(256)
         issued, clamp = C.c_double(0), C.c_double(0)
         _lib.call("oth_net_kernel_info", self._h, int(n_positions), name, 256, C.byref(issued), C.byref(clamp))
-        return {"kernel": name.value.decode(), "issued_per_flop": issued.value, "clamp": clamp.value}
+        return {"kernel": name.value.decode(), "issued_per_flop": issued.value, "clamp": clamp.value,
+                "act_scale": self.act_scale}
 
     def saturated(self):
-        """True when an fp16-split trunk launch since the last call clamped an activation (at 3750 in the direct
-        kernels, 1875 in the Winograd trunks that are the default for 10x128 on 8x8 and 5x64 on 6x6; the reference's
-        fp32 forward has no clamp): reads and clears the device flag (one 4-byte copy, synchronises the stream)."""
+        """True when an fp16-split trunk launch since the last call clamped an activation (at 60000 / act_scale in the
+        direct kernels, 30000 / act_scale in the Winograd trunks that are the default for 10x128 on 8x8 and 5x64 on 6x6:
+        3750 / 1875 at the default scale 16; the reference's fp32 forward has no clamp): reads and clears the device flag
+        (one 4-byte copy, synchronises the stream)."""
         flag = C.c_int32(0)
         _lib.call("oth_net_saturated", self._h, C.byref(flag), _lib.current_stream())
         return bool(flag.value)
 
+    @property
+    def act_scale(self):
+        """Power-of-two pre-scale of the activations in the fp16-split trunks (16 by default; 1.0 under 'f32')."""
+        s = C.c_float(0)
+        _lib.call("oth_net_get_act_scale", self._h, C.byref(s))
+        return float(s.value)
+
+    def needs_rescue(self):
+        """The reference's fp32 forward has no clamp (net.py:182-205), so a launch that clamped must not stand.  Called
+        by every worker / search mirror when a call's launches have ended (no launch of this network may be in flight):
+        False = nothing clamped, the results stand.  True = something did, and the evaluator has widened its range --
+        the activation scale halved (16 -> 8 -> 4 -> 2 -> 1: 1875 -> 30 000 in the Winograd trunks), or, if scale 1 still
+        clamped, the weights repacked for the exact-fp32 MFMA trunk -- so the caller must run the call again from the
+        state it started in (SearchEngine.snapshot / restore for a stream step or a lock-step search; a batch run
+        restarts from its seed; a search from its roots).  Seeded-random networks never get here; every rescue is
+        recorded in ``self.rescues`` and announced once per step with a warning."""
+        if self.precision == "f32" or not self.saturated():
+            return False
+        import warnings
+        info = self.kernel_info()
+        scale = self.act_scale
+        if scale > 1.0:
+            _lib.call("oth_net_set_act_scale", self._h, C.c_float(scale / 2))
+            what = "activation scale %g -> %g (clamp %g -> %g)" % (scale, scale / 2, info["clamp"], 2 * info["clamp"])
+        else:
+            self.precision = "f32"
+            self.refresh(force=True)
+            what = "still clamped at activation scale 1 (clamp %g): weights repacked for the exact-fp32 MFMA trunk" % info["clamp"]
+        self.saturated()   # (clear a flag raised by launches that were still in the call's tail)
+        self.rescues.append(what)
+        warnings.warn("an activation of the %dx%d network reached the range of the fp16-split trunk kernel %s; %s; the "
+                      "affected call is run again" % (self.num_blocks, self.num_filters, info["kernel"].split(" ")[0], what),
+                      RuntimeWarning, stacklevel=3)
+        return True
+
     def check_saturation(self):
-        """Loud failure instead of a silent deviation from the reference: called by the workers and the search mirrors
-        at the end of every call (they synchronise there anyway)."""
+        """Last line of defence (loud failure instead of a silent deviation from the reference): raises if a launch
+        clamped an activation and nobody rescued the call.  The workers and search mirrors use needs_rescue() and run the
+        call again; this is for callers that launch with rescue=False or drive the C ABI themselves."""
         if self.precision != "f32" and self.saturated():
             info = self.kernel_info()
             raise _lib.OthelloHipError(
-                "an activation of the %dx%d network exceeded %g, the range of the fp16-split trunk kernel %s: results "
-                "would differ from the reference's fp32 forward -- build the evaluator with precision='f32'"
-                % (self.num_blocks, self.num_filters, info["clamp"], info["kernel"].split(" ")[0]))
+                "an activation of the %dx%d network exceeded %g, the range of the fp16-split trunk kernel %s at activation "
+                "scale %g: results would differ from the reference's fp32 forward -- run the call again after "
+                "needs_rescue(), or build the evaluator with precision='f32'"
+                % (self.num_blocks, self.num_filters, info["clamp"], info["kernel"].split(" ")[0], self.act_scale))
 
     def policy_probs(self, logp):
         """exp(log-probs) with the engine's own expf (what the expansion feeds node.py:71-80): CUDA tensor in/out."""
@@ -268,6 +317,54 @@ class SearchEngine:
         _lib.call("oth_stream_step", self._h, int(min_games), C.byref(g), C.byref(n), _lib.current_stream())
         self._run_games = g.value
         return g.value, n.value
+
+    def snapshot(self):
+        """Keep the state of the stream / lock-step run as it is NOW (between two calls) ..."""
+        _lib.call("oth_engine_snapshot", self._h, _lib.current_stream())
+
+    def restore(self):
+        """... and put it back: the step / search since the snapshot is forgotten and can be played again (the rescue of
+        a saturated fp16-split launch, HipResNetEvaluator.needs_rescue)."""
+        _lib.call("oth_engine_restore", self._h, _lib.current_stream())
+
+    def _rescuable(self):
+        ev = self.evaluator
+        return ev is not None and getattr(ev, "precision", "f32") != "f32" and hasattr(ev, "needs_rescue")
+
+    def search_run_rescued(self):
+        """search_run from the roots of the last search_begin, repeated while a launch saturated."""
+        while True:
+            self.search_run()
+            if not (self._rescuable() and self.evaluator.needs_rescue()):
+                return
+            self.search_begin(*self._roots)
+
+    def selfplay_run_rescued(self, num_games, seed, add_noise=True):
+        """selfplay_run, restarted from its seed while a launch saturated (a run is a pure function of the seed)."""
+        while True:
+            n = self.selfplay_run(num_games, seed, add_noise)
+            if not (self._rescuable() and self.evaluator.needs_rescue()):
+                return n
+
+    def stream_step_rescued(self, min_games):
+        """stream_step from a snapshot, replayed while a launch saturated.  One engine per evaluator only: with several
+        lanes sharing an evaluator the snapshot / check / restore belongs at the point where all lanes have joined."""
+        while True:
+            if self._rescuable():
+                self.snapshot()
+            out = self.stream_step(min_games)
+            if not (self._rescuable() and self.evaluator.needs_rescue()):
+                return out
+            self.restore()
+
+    def selfplay_search_rescued(self):
+        while True:
+            if self._rescuable():
+                self.snapshot()
+            out = self.selfplay_search()
+            if not (self._rescuable() and self.evaluator.needs_rescue()):
+                return out
+            self.restore()
 
     def game_ids(self):
         """ids of the games of the last run / step, in output order."""

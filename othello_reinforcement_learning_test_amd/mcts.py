@@ -58,10 +58,8 @@ class MCTS:
         self.evaluator.refresh()
         eng = self._engine(num_simulations)
         eng.search_begin([board.self_board], [board.opp_board])
-        eng.search_run()
-        out = eng.search_results(temperature)
-        self.evaluator.check_saturation()
-        return out
+        eng.search_run_rescued()   # (a launch that clamped an activation is run again at a lower activation scale)
+        return eng.search_results(temperature)
 
     def search(self, board, num_simulations, temperature=1.0, add_dirichlet_noise=False):
         """-> (policy (65,) float32, root_value).  mcts.py:49-98."""

@@ -64,9 +64,8 @@ class BatchMCTS:
             pi, _, _, _ = eng.search_with(sb, ob, self.evaluator.host_eval, float(temperature))
         else:
             eng.search_begin(sb, ob)
-            eng.search_run()
+            eng.search_run_rescued()
             pi, _, _, _ = eng.search_results(float(temperature))
-            self.evaluator.check_saturation()
         return [(pi[i].copy(), 0.0) for i in range(n)]  # root value is always 0.0
 
 
@@ -147,7 +146,7 @@ class ParallelSelfPlayWorker:
         if self.lanes == 1 or num_episodes < 2 * self.lanes:
             self._grow_engine(num_episodes)
             self._ran = [self.engine]
-            n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
+            n = self.engine.selfplay_run_rescued(num_episodes, seed, add_dirichlet_noise)
             return self.engine.selfplay_fetch(n)[:3]
         self._ran = self._lane_engines
         import threading
@@ -169,13 +168,18 @@ class ParallelSelfPlayWorker:
                     out[k] = eng.selfplay_fetch(n)[:3]
             except BaseException as exc:   # re-raised in the calling thread: a failed lane fails the call
                 errors.append(exc)
-        threads = [threading.Thread(target=run, args=(k,)) for k in range(self.lanes)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        while True:
+            threads = [threading.Thread(target=run, args=(k,)) for k in range(self.lanes)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            # the lanes share one evaluator: the rescue of a saturated launch is decided here, where all of them have
+            # joined (no launch in flight), and every lane then restarts from its seed
+            if not self.batch_mcts.evaluator.needs_rescue():
+                break
         return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
 
     def _run_stream(self, num_episodes):
@@ -192,7 +196,7 @@ class ParallelSelfPlayWorker:
         cap = max(1, (self._hist_games - 2 * eng.max_games) // 2)
         left, parts, ids = int(num_episodes), [], []
         while left > 0:
-            g, n = eng.stream_step(min(left, cap))
+            g, n = eng.stream_step_rescued(min(left, cap))
             ids.append(eng.game_ids())
             parts.append(eng.selfplay_fetch(n)[:3])
             left -= g
@@ -221,7 +225,7 @@ class ParallelSelfPlayWorker:
             if add_dirichlet_noise:  # drawn inside search_batch, board by board (:111-118)
                 for i in active:
                     np.random.dirichlet([alpha] * len(boards[i].get_legal_moves()))
-            pi, _ = eng.selfplay_search()
+            pi, _ = eng.selfplay_search_rescued()
             actions = np.zeros(batch_size, dtype=np.int32)
             for i in active:  # :375-397
                 if ply[i] < self.temperature_threshold:
@@ -257,7 +261,7 @@ class ParallelSelfPlayWorker:
                 states, pis, zs = self._execute_batch_numpy(bs, add_dirichlet_noise)
                 data.extend(tuples_from_arrays(states, pis, zs))
                 done += bs
-        self.batch_mcts.evaluator.check_saturation()   # loud failure if the fp16-split trunk clamped an activation
+        self.batch_mcts.evaluator.check_saturation()   # last line of defence: every path above rescues a saturated launch
         dt = time.time() - t0
         counters = {}
         for eng in (self._ran if self.rng_mode == "device" else [self.engine]):
@@ -282,10 +286,8 @@ class ParallelSelfPlayWorker:
         if seed is None:
             seed = int(np.random.randint(0, 2**62))
         self._grow_engine(num_episodes)
-        n = self.engine.selfplay_run(num_episodes, seed, add_dirichlet_noise)
-        out = self.engine.selfplay_fetch(n)[:3]
-        self.batch_mcts.evaluator.check_saturation()
-        return out
+        n = self.engine.selfplay_run_rescued(num_episodes, seed, add_dirichlet_noise)
+        return self.engine.selfplay_fetch(n)[:3]
 
 
 def create_parallel_self_play_worker(config, model, device=None, **kwargs):

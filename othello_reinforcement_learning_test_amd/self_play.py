@@ -101,9 +101,8 @@ class SelfPlayWorker:
         self.mcts.evaluator.refresh()
         eng = self._device_engine(num_episodes)
         seed = int(np.random.randint(0, 2**62))
-        n = eng.selfplay_run(num_episodes, seed, add_dirichlet_noise)
+        n = eng.selfplay_run_rescued(num_episodes, seed, add_dirichlet_noise)
         states, pis, zs, _ = eng.selfplay_fetch(n)
-        self.mcts.evaluator.check_saturation()
         return tuples_from_arrays(states, pis, zs)
 
 

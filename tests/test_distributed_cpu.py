@@ -169,6 +169,8 @@ class _FakeEngine:
         self.calls += 1
         self._t = _make(1000 * self.calls + self.rank, 50 * n + self.rank)
 
+    selfplay_run_rescued = selfplay_run   # (SearchEngine's form that restarts a run whose network launches saturated)
+
     def selfplay_device_tensors(self):
         return self._t
 

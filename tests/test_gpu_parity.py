@@ -533,42 +533,219 @@ def test_wino6_variants_agree(pkg):
             os.environ["OTH_WINO6"] = old
 
 
-@pytest.mark.parametrize("blocks,filters,board", [(2, 128, 8), (2, 64, 8), (2, 32, 6)])
-def test_trunk_saturation_is_surfaced(pkg, blocks, filters, board):
-    """The fp16-split trunk kernels clamp activations at 3750; the reference's fp32 forward does not.  A network whose
-    activations go past the clamp must be REPORTED (oth_net_saturated -> OthelloHipError from the workers), never
-    silently different; the same weights under precision='f32' stay within tolerance of torch; an ordinary network
-    never raises the flag."""
-    torch.manual_seed(9)
+def _trained_like(pkg, blocks, filters, board, boost=1.0, seed=123):
+    """Non-trivial BatchNorm statistics, uneven per-channel scales, peaked policies (what a trained checkpoint looks like);
+    boost > 1: the stem's BatchNorm scaled up and the two head convolutions scaled down by the same factor, so the whole
+    trunk's activations are ~boost times larger while the outputs stay those of an ordinary network."""
+    torch.manual_seed(seed)
     net = pkg.OthelloResNet(blocks, filters, board_size=board).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 1.2 + 0.1)
+                mod.weight.copy_(torch.rand(mod.num_features, generator=g) * 1.8 + 0.3)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.mul_(torch.exp(torch.randn(mod.weight.shape[0], 1, 1, 1, generator=g) * 0.45))
+        net.policy_head.fc.weight.mul_(2.0)
+        if boost != 1.0:
+            net.conv_block.bn.weight.mul_(boost)
+            net.conv_block.bn.bias.mul_(boost)
+            net.policy_head.conv.weight.div_(boost)
+            net.value_head.conv.weight.div_(boost)
+    return net
+
+
+def _max_activation(net, x):
+    """largest post-ReLU activation of the trunk under torch fp32 (what the fp16-split kernels clamp)"""
+    mx = [0.0]
+    hooks = [m.register_forward_hook(lambda _m, _i, o: mx.__setitem__(0, max(mx[0], float(o.max()))))
+             for m in [net.conv_block] + list(net.res_blocks)]
+    with torch.no_grad():
+        out = net(x)
+    for h in hooks:
+        h.remove()
+    return mx[0], out
+
+
+@pytest.mark.parametrize("blocks,filters,board", [(6, 128, 8), (5, 64, 6), (3, 64, 8), (2, 32, 6)])
+def test_saturated_launch_is_rescued_by_a_lower_activation_scale(pkg, blocks, filters, board):
+    """The fp16-split trunks clamp activations at 1875 (Winograd trunks) / 3750 (direct ones) at their default activation
+    scale 16; the reference's fp32 forward (net.py:182-205) has no clamp.  Trained-like weights scaled until the trunk's
+    activations are in the thousands: the evaluator must NOT raise and must NOT return clamped outputs -- it halves the
+    scale until the range fits (needs_rescue), says which scale it chose, and the result is within 1e-4 of torch fp32.
+    An ordinary network never touches any of this."""
+    import warnings
     n = 130
     x = (torch.rand(n, 3, board, board, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    plain = _trained_like(pkg, blocks, filters, board)
+    ev0 = pkg.HipResNetEvaluator(plain)
+    assert ev0.precision == "f16x3" and ev0.act_scale == 16.0
+    ev0.forward_planes(x)
+    assert not ev0.saturated() and ev0.rescues == [] and ev0.act_scale == 16.0
+    # boost so that the largest activation is ~6000: beyond both clamps at scale 16, inside both at scale 4
+    amax1, _ = _max_activation(plain.cuda(), x)
+    plain.cpu()
+    net = _trained_like(pkg, blocks, filters, board, boost=6000.0 / amax1)
+    amax, (rl, rv) = _max_activation(net.cuda(), x)
+    net.cpu()
+    assert 3750 * 1.1 < amax < 7500 * 0.9, amax
     ev = pkg.HipResNetEvaluator(net)
-    assert ev.precision == "f16x3"
-    ev.forward_planes(x)
-    assert not ev.saturated()
-    ev.check_saturation()
-    with torch.no_grad():
-        net.conv_block.bn.weight.mul_(30000.0)          # stem output (and everything after it) far beyond 3750
-    ev.refresh()
-    ev.forward_planes(x)
-    torch.cuda.synchronize()
-    assert ev.saturated() and not ev.saturated()         # reported once, then cleared
-    ev.forward_planes(x)
+    clamp16 = ev.kernel_info(n)["clamp"]
+    assert clamp16 in (1875.0, 3750.0)
+    # (1) the raw launch reports the clamp (rescue=False: one asynchronous launch, flag left for the caller) ...
+    ev.forward_planes(x, rescue=False)
     with pytest.raises(pkg._lib.OthelloHipError):
         ev.check_saturation()
-    if filters != 128:   # the worker-level check (small network: a whole call takes a moment)
-        w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=2, num_parallel_games=4, verbose=False)
-        with pytest.raises(pkg._lib.OthelloHipError):
-            w.execute_episodes(2)
-    ev32 = pkg.HipResNetEvaluator(net, precision="f32")
-    logp, v = ev32.forward_planes(x)
+    assert not ev.saturated()                              # ... once: reading clears it
+    # (2) the default call rescues: no exception, a lower scale, outputs within tolerance
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        logp, v = ev.forward_planes(x)
+    info = ev.kernel_info(n)
+    assert ev.precision == "f16x3" and ev.act_scale < 16.0 and info["act_scale"] == ev.act_scale
+    assert ev.act_scale == 16.0 / 2 ** len(ev.rescues)
+    assert info["clamp"] == clamp16 * 16.0 / ev.act_scale and info["clamp"] > amax
+    assert len(ev.rescues) == len(wlist) >= 1 and "activation scale" in str(wlist[0].message)
+    e1, e2 = (logp - rl).abs().max().item(), (v - rv).abs().max().item()
+    print("\n    %dx%d on %dx%d, largest activation %.0f: rescued %d time(s) -> activation scale %g (clamp %g); max |dlogp| "
+          "%.2e, max |dv| %.2e vs torch fp32" % (blocks, filters, board, board, amax, len(ev.rescues), ev.act_scale,
+                                                 info["clamp"], e1, e2))
+    assert e1 < 1e-4 and e2 < 1e-4
+    assert not ev.saturated()
+    # (3) the scale is sticky across weight reloads, and the same call is now quiet
+    ev.refresh(force=True)
+    k = len(ev.rescues)
+    l2, v2 = ev.forward_planes(x)
+    assert len(ev.rescues) == k and torch.equal(l2, logp) and torch.equal(v2, v)
+
+
+def test_saturation_beyond_scale_one_falls_back_to_fp32(pkg):
+    """Activations of ~1e5 are beyond the fp16-split kernels at ANY scale (30 000 / 60 000 at scale 1): the evaluator walks
+    the scale down to 1 and then repacks for the exact-fp32 MFMA trunk -- still no exception."""
+    import warnings
+    torch.manual_seed(9)
+    net = pkg.OthelloResNet(2, 64).eval()
+    n = 130
+    x = (torch.rand(n, 3, 8, 8, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    with torch.no_grad():
+        net.conv_block.bn.weight.mul_(30000.0)
+    ev = pkg.HipResNetEvaluator(net)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        logp, v = ev.forward_planes(x)
+    assert ev.precision == "f32" and len(ev.rescues) == 5 == len(wlist) and "exact-fp32" in ev.rescues[-1]
+    assert ev.kernel_info(n)["kernel"].startswith("k_trunk_f32")
     with torch.no_grad():
         rl, rv = net.cuda()(x)
     net.cpu()
-    assert not ev32.saturated()
     # activations of ~1e5 here: fp32 rounding scales with them, so the check is relative (and the tanh is saturated)
     assert (logp - rl).abs().max().item() < 1e-4 * max(1.0, rl.abs().max().item()) and (v - rv).abs().max().item() < 2e-3
+
+
+def _run_stream_steps(eng, steps, rescued):
+    out = []
+    for m in steps:
+        g, ns = (eng.stream_step_rescued(m) if rescued else eng.stream_step(m))
+        out.append((eng.game_ids().copy(),) + tuple(a.copy() for a in eng.selfplay_fetch(ns)[:3]))
+    return out
+
+
+def test_rescue_replays_the_call_from_its_start_state(pkg):
+    """What 're-run the call from its start state' means for every kind of call, checked exactly: a worker whose
+    evaluator has to be rescued in the middle of its work returns the SAME tuples, bit for bit, as one whose evaluator
+    had the final activation scale from the start -- batch run (restart from the seed), stream step (snapshot / restore
+    of the slots, the queued roots, the status words and the history ring's bookkeeping; twice, the second time with
+    games in flight and finished games already harvested), lock-step search of the numpy-RNG worker, stand-alone search."""
+    import warnings
+    x = (torch.rand(64, 3, 8, 8, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    plain = _trained_like(pkg, 2, 64, 8)
+    amax1, _ = _max_activation(plain.cuda(), x)
+    net = _trained_like(pkg, 2, 64, 8, boost=6000.0 / amax1)   # k_trunk_h3: clamp 3750 at scale 16, 7500 at 8
+
+    def fresh(scale=None):
+        ev = pkg.HipResNetEvaluator(net)
+        if scale is not None:
+            pkg._lib.call("oth_net_set_act_scale", ev.handle, C.c_float(scale))
+        return ev
+
+    def set_scale(ev, s):
+        pkg._lib.call("oth_net_set_act_scale", ev.handle, C.c_float(s))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # ---- find the scale the rescue settles at (self-play visits positions the probe batch above does not)
+        ev = fresh()
+        eng = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev)
+        n = eng.selfplay_run_rescued(24, seed=5)
+        a = eng.selfplay_fetch(n)
+        final = ev.act_scale
+        assert final < 16.0 and len(ev.rescues) >= 1
+        # batch run: identical to a run at the final scale from the start
+        ev_ref = fresh(final)
+        eng_ref = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev_ref)
+        b = eng_ref.selfplay_fetch(eng_ref.selfplay_run(24, seed=5))
+        assert ev_ref.rescues == [] and not ev_ref.saturated()
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+        # ---- streaming: step 1 is rescued from the stream's start, step 3 (scale put back to 16 by hand) with games in
+        #      flight, finished games harvested and the ring partly released
+        steps = (10, 7, 9, 5)
+        ref = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev_ref)
+        ref.stream_begin(77, stagger_rounds=5)
+        want = _run_stream_steps(ref, steps, rescued=False)
+        ev2 = fresh()
+        e2 = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev2)
+        e2.stream_begin(77, stagger_rounds=5)
+        got = _run_stream_steps(e2, steps[:2], rescued=True)
+        assert ev2.act_scale == final and len(ev2.rescues) >= 1
+        set_scale(ev2, 16.0)
+        k = len(ev2.rescues)
+        got += _run_stream_steps(e2, steps[2:], rescued=True)
+        assert ev2.act_scale == final and len(ev2.rescues) > k
+        for w_, g_ in zip(want, got):
+            assert all(np.array_equal(p, q) for p, q in zip(w_, g_))
+        assert e2.counters() == ref.counters()
+        # ---- lock-step search (the numpy-RNG worker's path) and the stand-alone search
+        ev3 = fresh()
+        e3 = pkg.SearchEngine(4, 6, evaluator=ev3)
+        e3.selfplay_begin(4)
+        pi, act = e3.selfplay_search_rescued()
+        r3 = pkg.SearchEngine(4, 6, evaluator=ev_ref)
+        r3.selfplay_begin(4)
+        pi_ref, act_ref = r3.selfplay_search()
+        assert ev3.act_scale == final and np.array_equal(pi, pi_ref) and np.array_equal(act, act_ref)
+        set_scale(ev3, 16.0)
+        actions = pi.argmax(1).astype(np.int32)
+        e3.selfplay_apply(actions)
+        r3.selfplay_apply(actions)
+        pi, _ = e3.selfplay_search_rescued()             # rescued again, one ply into the games
+        pi_ref, _ = r3.selfplay_search()
+        assert ev3.act_scale == final and np.array_equal(pi, pi_ref)
+        roots = game_positions(3, 5)[:8]
+        s, o = [p[0] for p in roots], [p[1] for p in roots]
+        set_scale(ev3, 16.0)
+        e4 = pkg.SearchEngine(8, 10, evaluator=ev3)
+        e4.search_begin(s, o)
+        e4.search_run_rescued()
+        r4 = pkg.SearchEngine(8, 10, evaluator=ev_ref)
+        r4.search_begin(s, o)
+        r4.search_run()
+        assert ev3.act_scale == final
+        assert all(np.array_equal(p, q) for p, q in zip(e4.search_results(1.0), r4.search_results(1.0)))
+        # ---- the drop-in worker, end to end: no exception, same tuples as a worker that never needed a rescue
+        np.random.seed(11)
+        w1 = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=4, num_parallel_games=8, verbose=False)
+        d1 = w1.execute_episodes(6)
+        assert w1.batch_mcts.evaluator.act_scale < 16.0 and len(w1.batch_mcts.evaluator.rescues) >= 1
+        np.random.seed(11)
+        w2 = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=4, num_parallel_games=8, verbose=False)
+        set_scale(w2.batch_mcts.evaluator, w1.batch_mcts.evaluator.act_scale)
+        d2 = w2.execute_episodes(6)
+        assert w2.batch_mcts.evaluator.rescues == []
+        assert len(d1) == len(d2) and all(np.array_equal(p[0], q[0]) and np.array_equal(p[1], q[1]) and p[2] == q[2]
+                                          for p, q in zip(d1, d2))
 
 
 def test_trunk_on_trained_like_weights(pkg):
