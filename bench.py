@@ -6,6 +6,12 @@ per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the e
 warmup steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize(), MAX over
 ranks; rank 0 prints ONE JSON line on stdout (and a heartbeat line per step on stderr).
 
+A PLAIN `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) launches itself: before torch or the
+package is imported -- before anything touches a GPU -- this process starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD (never an exec),
+relays its output and exits with its return code.  A WORLD_SIZE that disagrees with --gpus is an error (exit 2), never a
+silent single-GPU run that prints "n_gpus": 1.
+
 Workload (BASELINE.json configs[1]): 4096 concurrent 8x8 self-play games per GPU, 50 simulations per move,
 10-block x 128-filter network with seeded-random weights (torch.manual_seed(42)), c_puct 1.0, temperature
 threshold 15, every position the search reaches evaluated by the network -- entirely on the device.
@@ -341,6 +347,58 @@ def run_leg(pkg, torch, name, note, board, blocks, filters, sims, games, step_ga
     return out
 
 
+def launch_ranks(n_ranks, argv):
+    """--gpus N > 1 outside a torch.distributed.run environment: run the N ranks as a child process group and return its
+    exit code.  This (parent) process never imports torch and never touches a GPU; it only relays -- the child inherits
+    stdout (rank 0's JSON line) and stderr (heartbeats) -- and forwards SIGTERM / SIGINT to the whole group."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] --gpus %d without WORLD_SIZE: starting %d ranks as a child: %s" % (n_ranks, n_ranks, " ".join(cmd[1:9])),
+          file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTHELLO_BENCH_SELF_LAUNCHED="1")
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)   # own group: torchrun and its ranks end together
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(proc.pid, signum)
+        except ProcessLookupError:
+            pass
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, forward)
+    try:
+        rc = proc.wait()
+    finally:
+        try:   # nothing of the group may outlive this process
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+    return rc if rc >= 0 else 128 - rc
+
+
+def check_world(args, argv):
+    """The launch environment against --gpus, BEFORE torch / the package / the GPU: returns None to go on as one rank of
+    the job, or the exit code of the self-launched job."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is None and "RANK" not in os.environ:
+        return launch_ranks(args.gpus, argv) if args.gpus > 1 else None
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launch environment has WORLD_SIZE=%s: start it as `python bench.py --gpus %d ...` "
+              "(it launches its own ranks) or under `python -m torch.distributed.run --nproc-per-node %d`"
+              % (args.gpus, env_world, args.gpus, args.gpus), file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +437,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     args = ap.parse_args()
+    rc = check_world(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
 
     t_start = time.time()
     # (re)build the CPU oracle now: no fork+exec once this process holds the GPU.  Only the single-process run times the
@@ -394,10 +455,16 @@ def main():
     from othello_reinforcement_learning_test_amd import distributed as D
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    pkg._lib.require_device()   # no GPU => fail loudly
+    assert world == args.gpus, (world, args.gpus)   # (check_world above)
+    try:
+        pkg._lib.require_device()   # no GPU => fail loudly
+    except Exception as exc:
+        raise SystemExit("bench.py rank %d/%d: %s" % (rank, world, exc))
     import torch.distributed as dist
+    if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py rank %d/%d: %d ranks need %d GPUs, this node shows %d (RCCL needs one GPU per rank; "
+                         "OTHELLO_DIST_BACKEND=gloo rehearses the control flow on fewer)"
+                         % (rank, world, world, world, torch.cuda.device_count()))
 
     def beat(msg):
         if rank == 0:
@@ -438,6 +505,8 @@ def main():
         dist.all_gather_into_tensor(allr, t)
         shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
 
+    xchg = {"s": 0.0, "n": 0}   # time of the exchange step inside the timed region (this rank)
+
     def step():
         """-> (games this rank finished, replay samples of the whole job after the exchange)"""
         mine = shares[rank]
@@ -445,9 +514,13 @@ def main():
         games, parts = wl.play(mine)
         t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
+            t_x = time.time()
             st, pi, z = ([p_[j].cpu() if gloo else p_[j] for p_ in parts] for j in range(3))   # one part per lane
             st, pi, z, _ = D.all_gather_replay(st, pi, z, force=True)   # persistent buffers: no per-step allocation
             samples = int(z.shape[0])
+            torch.cuda.synchronize()   # (the collectives are asynchronous: the exchange is timed to its end)
+            xchg["s"] += time.time() - t_x
+            xchg["n"] += 1
         else:          # single GPU: the tuples stay where the lanes compacted them (no copy)
             samples = sum(int(p_[2].shape[0]) for p_ in parts)
         rebalance(games, t_play)
@@ -475,6 +548,7 @@ def main():
         beat("warm-up step %d/%d: %d games in %.2f s" % (i + 1, args.warmup, g, time.time() - t1))
     barrier()
     c0 = counters()
+    xchg["s"], xchg["n"] = 0.0, 0
     t0 = time.time()
     my_games, samples = 0, 0
     for i in range(args.steps):
@@ -488,12 +562,20 @@ def main():
     dt = time.time() - t0
     c1 = counters()
     total_games = my_games
+    per_rank_rate, exchange_ms = [my_games / max(dt, 1e-9)], None
     if use_dist:
-        t = torch.tensor([dt, float(my_games)], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        t = torch.tensor([dt, float(my_games), xchg["s"] * 1e3 / max(1, xchg["n"])], dtype=torch.float64,
+                         device="cpu" if gloo else "cuda")
+        mine_t = t.clone()
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        allr = torch.zeros(3 * world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allr, mine_t)
+        allr = allr.cpu().view(world, 3)
+        per_rank_rate = [round(float(allr[r, 1] / max(float(allr[r, 0]), 1e-9)), 2) for r in range(world)]
         dt, total_games = float(tmax[0].item()), int(round(float(t[1].item())))
+        exchange_ms = round(float(tmax[2].item()), 3)   # the slowest rank's mean exchange time per timed step
     stats = {k: c1[k] - c0.get(k, 0) for k in c1}
 
     # ---- profiled step(s) outside the timed region: HIP-event spans of every trunk launch ------------------------
@@ -543,6 +625,13 @@ def main():
             "value": round(total_games / dt, 3),
             "unit": "games/s",
             "n_gpus": world,
+            "ranks": dist.get_world_size() if use_dist else 1,
+            "backend": ("none (single process)" if not use_dist else
+                        ("gloo (REHEARSAL on host copies)" if gloo else "nccl (= RCCL)")),
+            "per_rank_games_per_s": per_rank_rate,
+            "exchange_ms_per_step": exchange_ms,
+            "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("OTHELLO_BENCH_SELF_LAUNCHED")
+                            else ("torch.distributed.run of the caller" if "RANK" in os.environ else "single process")),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2),

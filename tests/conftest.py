@@ -49,19 +49,29 @@ def pytest_sessionstart(session):
 
 
 def pytest_sessionfinish(session, exitstatus):
+    """Never leave ranks behind.  The launcher's SIGTERM handler ends the stage that is running -- every process under it,
+    whatever its session (tests/gpu_children.py: the stages run in their own sessions, and bench.py's self-launch starts
+    its ranks in yet another) -- and exits; if it does not, its whole tree is collected as exact PIDs and killed here."""
     p = CHILDREN["proc"]
-    if p is not None and p.poll() is None:   # never leave ranks behind: end the launcher's own process group
-        import signal
-        for sig in (signal.SIGTERM, signal.SIGKILL):
-            try:
-                os.killpg(p.pid, sig)
-            except ProcessLookupError:
-                break
-            try:
-                p.wait(timeout=20)
-                break
-            except Exception:
-                pass
+    if p is None or p.poll() is not None:
+        return
+    import signal
+    import psutil
+    try:
+        tree = [psutil.Process(p.pid)] + psutil.Process(p.pid).children(recursive=True)
+    except psutil.NoSuchProcess:
+        tree = []
+    p.send_signal(signal.SIGTERM)
+    try:
+        p.wait(timeout=40)
+    except Exception:
+        pass
+    for q in tree:   # whatever survived the launcher's own clean-up
+        try:
+            q.kill()
+        except psutil.NoSuchProcess:
+            pass
+    psutil.wait_procs(tree, timeout=10)
 
 
 @pytest.fixture(scope="session")

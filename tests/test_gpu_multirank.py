@@ -2,7 +2,9 @@
 rotting while no multi-GPU node is available.  Three child stages, run one after the other by tests/gpu_children.py (started
 by tests/conftest.py at session start, before this process initialises the GPU):
 
-* ``rehearsal``    bench.py's N>1 path by FOUR ranks sharing GPU 0, collectives over gloo (RCCL needs one GPU per rank; the
+* ``rehearsal``    a PLAIN ``python bench.py --gpus 4`` (no torch.distributed.run around it: bench.py launches its own ranks
+                   as a child process before it touches the GPU -- what an 8-GPU node's first contact runs): the N>1 path
+                   by FOUR ranks sharing GPU 0, collectives over gloo (RCCL needs one GPU per rank; the
                    box admits six processes on its card, so eight ranks cannot share it -- the world-size-8 exchange step
                    runs on CPU tensors in tests/test_distributed_cpu.py);
 * ``rccl_bench``   the SAME code path on a ONE-RANK nccl (= RCCL) group (OTHELLO_FORCE_DIST=1, torch.distributed.run
@@ -39,6 +41,10 @@ def _check_small_bench(d, w, err):
     assert rr["bound"] == "hbm" and rr["unit"] == "GB/s" and rr["achieved"] > 0 and rr["launches"] > 0
     assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-4
     assert "step 2/2" in err                            # heartbeat lines on stderr
+    # the N>1 line says how many ranks really ran, what each of them did and what the exchange cost
+    assert d["ranks"] == w and len(d["per_rank_games_per_s"]) == w and all(r > 0 for r in d["per_rank_games_per_s"])
+    assert abs(sum(d["per_rank_games_per_s"]) - d["value"]) < 0.25 * d["value"]   # (each rank's own clock vs the slowest's)
+    assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
 
 
 def test_bench_multi_rank_rehearsal(children):
@@ -48,6 +54,10 @@ def test_bench_multi_rank_rehearsal(children):
     _check_small_bench(d, children.ranks, err)
     par = d["config"]["parallelism"]
     assert "REHEARSAL" in par and "gloo" in par         # never reads as an RCCL measurement
+    assert d["backend"].startswith("gloo")
+    # the stage is a PLAIN `python bench.py --gpus 4`: bench.py itself started the four ranks as a child
+    assert d["launched_by"].startswith("bench.py itself")
+    assert "--gpus 4 without WORLD_SIZE: starting 4 ranks as a child" in err
 
 
 def test_bench_n_gt_1_path_on_rccl_one_rank(children):
@@ -58,6 +68,7 @@ def test_bench_n_gt_1_path_on_rccl_one_rank(children):
     _check_small_bench(d, 1, err)
     par = d["config"]["parallelism"]
     assert "RCCL all-gather" in par and "REHEARSAL" not in par and "gloo" not in par
+    assert d["backend"].startswith("nccl") and d["launched_by"].startswith("torch.distributed.run")
     assert "one-rank group" in par                      # and never reads as a multi-GPU measurement either
 
 
