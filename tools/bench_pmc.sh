@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side traffic of bench.py's OWN launches (two lanes, ~2 000 positions per trunk launch): separate rocprofv3 --pmc passes
-# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/r04_bench_traffic.json
+# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/r05_bench_traffic.json
 # (copy it to profiles/: bench.py reads roofline.traffic and roofline_rollout.traffic from there) and a text summary.
 set -e
 cd "$(dirname "$0")/.."
@@ -15,8 +15,10 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "tcc TCC_HIT_sum TCC_MISS_sum 
 done
 cat "$out/summary.txt"
 python3 - "$out" "$CMD" <<'PY'
-import json, re, sys
+import importlib.util, json, re, sys
 out, cmd = sys.argv[1], sys.argv[2]
+spec = importlib.util.spec_from_file_location("bench", "bench.py")
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 vals = {}
 for ln in open(out + "/summary.txt"):
     m = re.match(r"(\w+) (oth::[\w<>, ]+?) (\{.*\})$", ln.strip())
@@ -29,7 +31,8 @@ for ln in open(out + "/summary.txt"):
     vals[kern]["launches"] = int(n.group(1))
 line = [l for l in open(out + "/fetch.json") if l.startswith("{")][-1]
 ppl = json.loads(line)["roofline"]["positions_per_launch"]
-res = {"command": cmd, "source": "rocprofv3 --kernel-trace --pmc, one pass per counter group, per-launch means over all launches of the run", "kernels": {}}
+res = {"command": cmd, "kernel_source_sha256": bench.trunk_source_sha256(), "kernel_sources": list(bench.TRUNK_SOURCES),
+       "source": "rocprofv3 --kernel-trace --pmc, one pass per counter group, per-launch means over all launches of the run", "kernels": {}}
 for kern, v in vals.items():
     key = "trunk" if ("k_trunk16" in kern or "k_trunk_w" in kern) else ("k_tree" if kern.startswith("oth::k_tree<1") else None)
     if key is None or "FETCH_SIZE" not in v:
@@ -46,7 +49,7 @@ for kern, v in vals.items():
     }
     if wide:
         res["kernels"][key]["positions_per_launch"] = ppl
-json.dump(res, open("gpurun_out/r04_bench_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r05_bench_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf "$out"/fetch "$out"/write "$out"/tcc

@@ -40,7 +40,7 @@ for spec in args.nets.split(","):
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(reps):
-        ev.forward_bits(*bits)
+        ev.forward_bits(*bits, rescue=False)   # back-to-back asynchronous launches (the rescue check synchronises)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / reps
     mf = bench.mflop_per_position(nb, nf) * (bs * bs / 64.0)   # conv work scales with the cells (heads are negligible)
