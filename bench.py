@@ -69,22 +69,30 @@ def mflop_per_position(blocks, filters, board=8):
     return 2.0 * macs / 1e6
 
 
-# Planned wall-clock of the three `other_configs` legs at the planning rate (measured on the box: configs[3] ~45 s incl.
-# its staggered ramp, configs[4] ~20 s, the evaluation-cache run of configs[1] ~25 s); they are skipped when the run is
-# already past LEGS_DEADLINE seconds (a slow box, a cold start), so they can never push the headline out of the limit.
-OTHER_LEGS_SECONDS = 90.0
-LEGS_DEADLINE = 330.0
+# The secondary legs (`other_configs`), in the order they run, with the wall-clock each took on the box at MEASURED_RATE
+# games/s on the headline (round 5: configs[3] with 4416 slots incl. its staggered ramp, configs[4], configs[1] + evaluation
+# cache with 8192 slots).  A leg starts only if 1.5 x its (rate-scaled) seconds still fit before LEGS_HARD_STOP seconds of
+# process life, so a slow box or a cold start drops legs -- last ones first -- instead of running into the driver's limit.
+LEG_SECONDS = (("configs[3]", 67.0), ("configs[4]", 12.0), ("configs[1] + eval cache", 32.0))
+MEASURED_RATE = 615.0
+OTHER_LEGS_SECONDS = sum(s for _, s in LEG_SECONDS)
+LEGS_HARD_STOP = 530.0
+DRIVER_LIMIT = 600.0
 
 
 def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_steps=1, cpu_budget=15.0,
-                    rate=PLANNING_RATE, startup=150.0, other_legs=OTHER_LEGS_SECONDS):
+                    rate=PLANNING_RATE, startup=150.0, legs=True):
     """Wall-clock plan of one bench.py run on one MI355X (default workload): process start-up (the first
     `import torch` on a fresh box can take 2 minutes) + staggered ramp + (warmup + steps + profiled) steps +
-    the secondary legs (scaled with the rate; none past LEGS_DEADLINE) + CPU baseline."""
+    the secondary legs that still fit (each scaled with the rate, admitted by the rule above) + CPU baseline (its budget
+    + the ply in flight when the budget ends, ~ 40 %)."""
     ramp = 0.5 * slots * min(stagger, 61) / 61.0 / rate          # half-full slots during the staggered start
-    head = startup + ramp + (warmup + steps + profile_steps) * step_games / rate
-    legs = other_legs * PLANNING_RATE / rate if head <= LEGS_DEADLINE else 0.0
-    return head + legs + cpu_budget + 10.0
+    t = startup + ramp + (warmup + steps + profile_steps) * step_games / rate
+    for _, sec in (LEG_SECONDS if legs else ()):
+        sec = sec * MEASURED_RATE / rate
+        if t + 1.5 * sec <= LEGS_HARD_STOP:
+            t += sec
+    return t + 1.4 * cpu_budget + 10.0
 
 
 TRUNK_SOURCES = ("net_wino.hip", "net_epilogue.h", "net_heads.h", "net.h", "Makefile")
@@ -134,41 +142,57 @@ def committed_traffic(kernel_name):
     return out
 
 
-def cpu_baseline(net, sims, budget_s, evals_per_game):
-    """Time the oracle (kind 'port') on the host cores: one serial self-play stream per core, each starting at a
-    different phase of a game (so openings, middle games and endgames are sampled like a whole game), a bounded
-    number of plies each."""
+def cpu_baseline(net, sims, budget_s, evals_per_game, min_plies=4):
+    """Time the oracle (kind 'port') on the host: one serial self-play stream per PHYSICAL core of this process's affinity
+    mask, stream s starting 58*s/streams random plies into a game (phase-uniform: openings, middle games and endgames are
+    sampled like a whole game), each playing whole plies until `budget_s` seconds have passed and it has played at least
+    `min_plies` -- a bounded sample, with the spread of the per-stream rates reported beside the total.  (One stream per
+    hardware THREAD was measured and is slower: 256 streams on the box's 256 threads gave 0.32 games/s against 0.56-0.59 with
+    128 -- SMT siblings share the FMA units, and 256 private 12 MB weight sets thrash the last-level cache;
+    profiles/r05_bench_driver_cmd_run1.json.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import oracle_lib as ol
     try:
-        cores = len(os.sched_getaffinity(0))
+        hw_threads = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        hw_threads = os.cpu_count() or 1
+    cores = hw_threads
+    try:   # physical cores: hardware threads / SMT width of the machine
+        import psutil
+        logical, physical = psutil.cpu_count(logical=True), psutil.cpu_count(logical=False)
+        if logical and physical and logical > physical:
+            cores = max(1, hw_threads * physical // logical)
+    except Exception:
+        pass
     onet = ol.Net(net.num_blocks, net.num_filters, ol.state_dict_blob(net.state_dict()))
     cfg = ol.SelfplayCfg(sims, 15, 1, 1.0, 0.3, 0.25, 1, 0)
-
-    def run(plies):
-        ev, th, ended = C.c_int64(0), C.c_int(0), C.c_int64(0)
-        t0 = time.time()
-        n = ol.lib().orc_cpu_baseline_spread(onet.h, C.byref(cfg), cores, plies, 58, 42, C.byref(ev), C.byref(th),
-                                             C.byref(ended))
-        return n, ev.value, th.value, time.time() - t0
-    n, ev, th, dt = run(1)                       # calibration: one ply per stream
-    plies = max(1, min(20, int(budget_s / max(dt, 1e-3))))
-    if plies > 1:
-        n, ev, th, dt = run(plies)
+    plies = np.zeros(cores, dtype=np.int32)
+    secs = np.zeros(cores, dtype=np.float64)
+    ev, th, ended = C.c_int64(0), C.c_int(0), C.c_int64(0)
+    t0 = time.time()
+    n = ol.lib().orc_cpu_baseline_timed(onet.h, C.byref(cfg), cores, cores, int(min_plies), float(budget_s), 58, 42,
+                                        plies.ctypes.data_as(C.POINTER(C.c_int32)), secs.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(ev), C.byref(th), C.byref(ended))
+    dt = time.time() - t0
+    rate = plies / np.maximum(secs, 1e-9)            # plies/s of each stream on its own clock
     out = {
-        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th, "streams": cores, "kind": "port",
-        "cores_note": "`cores` = OpenMP threads that ran the sample (what the library reports), `streams` = independent "
-                      "self-play streams = hardware threads in this process's affinity mask; streams are dealt to the threads",
-        "sample": "%d plies (%d network evals) of serial self-play on %d streams, stream s starting 58*s/%d random "
-                  "plies into a game (phase-uniform: openings to endgames), %d plies each, 10x128 net fp32, %d "
-                  "sims/move, %.1f s; scaled with %.1f plies/game (the engine's measured game length)"
-                  % (n, ev, cores, cores, plies, sims, dt, PLIES_PER_GAME),
-        "evals_per_s": round(ev / dt, 1),
+        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th.value, "streams": cores,
+        "hardware_threads": hw_threads, "kind": "port",
+        "sample": "%d plies (%d network evals) of serial self-play, one stream per physical core (%d streams on %d OpenMP "
+                  "threads), stream s starting 58*s/%d random plies into a game (phase-uniform: openings to endgames), %d-%d "
+                  "plies each (>= %d, until %.0f s had passed), %dx%d net fp32, %d sims/move, %.1f s of wall clock; scaled "
+                  "with %.1f plies/game (the engine's measured game length)"
+                  % (n, ev.value, cores, th.value, cores, int(plies.min()), int(plies.max()), min_plies, budget_s,
+                     net.num_blocks, net.num_filters, sims, dt, PLIES_PER_GAME),
+        "evals_per_s": round(ev.value / dt, 1),
+        "per_stream_plies_per_s": {"min": round(float(rate.min()), 4), "median": round(float(np.median(rate)), 4),
+                                   "max": round(float(rate.max()), 4),
+                                   "note": "each stream's plies over its own busy time; value uses the total over the wall clock"},
+        "value_spread": [round(float(rate.min()) * cores / PLIES_PER_GAME, 5), round(float(rate.max()) * cores / PLIES_PER_GAME, 5)],
     }
     if evals_per_game:
-        out["value_by_evals"] = round(ev / dt / evals_per_game, 5)
+        out["value_by_evals"] = round(ev.value / dt / evals_per_game, 5)
     return out
 
 
@@ -306,6 +330,13 @@ class Workload:
                 tot[k] = tot.get(k, 0) + v
         return tot
 
+    def cache_stats(self):
+        tot = {}
+        for e_ in self.engs:
+            for k, v in e_.cache_stats().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
     def set_timing(self, on):
         for e_ in self.engs:
             e_.set_timing(on)
@@ -347,8 +378,8 @@ class Workload:
         gc.collect()
 
 
-def run_leg(pkg, torch, name, note, board, blocks, filters, sims, games, step_games, warmup, steps, c_puct=1.0,
-            temp_threshold=15, eval_cache=0, lanes=2, stagger=61):
+def run_leg(pkg, torch, name, note="", board=8, blocks=10, filters=128, sims=50, games=4096, step_games=1536, warmup=2, steps=4,
+            c_puct=1.0, temp_threshold=15, eval_cache=0, lanes=2, stagger=61):
     """A short secondary measurement in the same process (N = 1 only, after the headline's timed region and profiled
     step): the same streaming schedule on another BASELINE configuration -> a small dict for `other_configs`."""
     t_leg = time.time()
@@ -358,17 +389,19 @@ def run_leg(pkg, torch, name, note, board, blocks, filters, sims, games, step_ga
         w.play(step_games)
     torch.cuda.synchronize()
     c0, t0, n = w.counters(), time.time(), 0
+    cs0 = w.cache_stats() if eval_cache else None
     for _ in range(steps):
         n += w.play(step_games)[0]
     torch.cuda.synchronize()
     dt = time.time() - t0
     c1 = w.counters()
     st = {k: c1[k] - c0.get(k, 0) for k in c1}
+    cs1 = w.cache_stats() if eval_cache else None
     prof = w.profiled_steps(1, lambda: w.play(step_games)[0])
     achieved, peak, info = w.roofline_numbers(prof)
     w.ev.check_saturation()
     out = {
-        "config": name, "note": note, "value": round(n / dt, 2), "unit": "games/s", "games_timed": n,
+        "config": name, "value": round(n / dt, 2), "unit": "games/s", "games_timed": n,
         "seconds_timed": round(dt, 2), "steps": steps, "warmup": warmup, "step_games": step_games,
         "concurrent_games": games, "lanes": lanes,
         "workload": "%dx%d, %d sims/move, %d-block x %d ResNet, c_puct %.2f, temperature threshold %d"
@@ -386,9 +419,17 @@ def run_leg(pkg, torch, name, note, board, blocks, filters, sims, games, step_ga
     }
     if eval_cache:
         hits = st.get("cache_hits", 0)
-        out["eval_cache"] = {"log2_entries": eval_cache, "hits": hits,
+        cst = {k: cs1[k] - cs0[k] for k in ("distinct_positions", "repeated_evals", "conflict_evictions")}
+        out["eval_cache"] = {"log2_entries_per_lane": eval_cache, "hits": hits,
                              "hit_rate": round(hits / max(1, hits + st["evals"]), 4),
-                             "positions_reached_per_game": round((hits + st["evals"]) / max(1, st["games"]), 1)}
+                             "positions_reached_per_game": round((hits + st["evals"]) / max(1, st["games"]), 1),
+                             # the misses, split: first evaluation of a position since the step's clear (compulsory) vs a
+                             # position evaluated again (its entry was replaced in between, or a double miss in one launch)
+                             "compulsory_misses": cst["distinct_positions"], "repeat_misses": cst["repeated_evals"],
+                             "conflict_evictions": cst["conflict_evictions"],
+                             "repeat_share_of_misses": round(cst["repeated_evals"] / max(1, st["evals"]), 4)}
+    if note:
+        out["note"] = note
     w.close()
     out["leg_seconds"] = round(time.time() - t_leg, 1)
     return out
@@ -482,7 +523,9 @@ def main():
                          "trunk launch duration over all launches of the run: the figure a rocprofv3 --kernel-trace "
                          "--stats of the same command must reproduce.  Not the headline configuration.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
+    ap.add_argument("--cpu-budget", type=float, default=15.0,
+                    help="seconds of CPU work for the baseline (every stream plays whole plies until this much time has passed "
+                         "and it has played at least 4: ~20 s of wall clock)")
     args = ap.parse_args()
     rc = check_world(args, sys.argv[1:])
     if rc is not None:
@@ -761,45 +804,56 @@ def main():
         # ---- short secondary legs: the other single-GPU BASELINE configurations, driver-run in the same process --------
         headline = (args.board, args.blocks, args.filters, args.sims, args.games, args.eval_cache, args.precision) == \
             (8, 10, 128, 50, 4096, 0, None)
-        if headline and not use_dist and not args.no_other_configs and time.time() - t_start > LEGS_DEADLINE:
-            out["other_configs"] = [{"skipped": "the run was already %.0f s old (deadline %.0f s)"
-                                                % (time.time() - t_start, LEGS_DEADLINE)}]
-        elif headline and not use_dist and not args.no_other_configs:
+        if headline and not use_dist and not args.no_other_configs:
             wl.close()
             engs = []
+            # configs[3]: 4608 slots in THREE lanes of 1536.  The tree kernel of a 400-simulation search is ~0.4 ms per launch
+            # beside a trunk launch of ~1.4 ms, so with two lanes there are moments when both are in it (trunk share of the
+            # step 0.94-0.97, 76.7-77.3 games/s at 4096-4416 slots); the third lane keeps a trunk launch running (0.996;
+            # profiles/r05_sweep_configs3.txt: 80.2 games/s, the same as 6624 slots in three lanes at a shorter ramp).
+            # configs[1] + cache: 8192 slots in two lanes and steps of 3072 games (the same slots : step ratio as the
+            # headline, so a game sees as many cache clears), so that a launch of the MISSES is again ~1 350 positions
+            # (profiles/r05_sweep_cache.txt: 1 663 vs 1 498 games/s at 4096 slots), and 2^24 entries per lane (4.9 GB of the
+            # 288: repeated evaluations 9.8 % -> 5.0 % of the misses, +5 %: profiles/r05_sweep_cache_b.txt).
             legs = (
-                dict(name="configs[3]", note="BASELINE configs[3]: 400 sims/move, c_puct 1.5, temperature threshold 20 "
-                     "(deep trees); 2048 concurrent games so that the staggered ramp fits the leg",
-                     board=8, blocks=10, filters=128, sims=400, games=2048, step_games=256, warmup=2, steps=4,
+                dict(name="configs[3]", board=8, blocks=10, filters=128, sims=400, games=4608, lanes=3, step_games=255, warmup=2, steps=4,
                      c_puct=1.5, temp_threshold=20),
-                dict(name="configs[4]", note="BASELINE configs[4]: 6x6 board, 25 sims/move, 5x64 network -- 6x6 RULES "
-                     "PARITY UNPINNED (the reference implements no 6x6 game; network pinned by its own outputs, rules checked "
-                     "against the 6x6 build of the CPU oracle only); 6144 concurrent games in three lanes of 2048 (k_trunk_w6 fills "
-                     "a CU with one workgroup, so a third lane is what keeps a trunk launch running while two lanes are in their "
-                     "tree kernels: 28.1 k games/s against 27.0 k with 4096 games in two lanes)",
+                dict(name="configs[4]", note="6x6 RULES PARITY UNPINNED (the reference implements no 6x6 game)",
                      board=6, blocks=5, filters=64, sims=25, games=6144, lanes=3, step_games=32769, warmup=3, steps=4),
-                dict(name="configs[1] + eval cache", note="configs[1] with the opt-in evaluation cache ON (2^22 entries per "
-                     "lane): a transposition table of network outputs, every (state, pi, z) bit-identical, but network "
-                     "evaluations are SKIPPED on hits -- NOT the headline configuration, never `value`",
-                     board=8, blocks=10, filters=128, sims=50, games=4096, step_games=1536, warmup=5, steps=8,
-                     eval_cache=22),
+                dict(name="configs[1] + eval cache", note="evaluation cache ON: NOT the headline configuration, never `value`",
+                     board=8, blocks=10, filters=128, sims=50, games=8192, step_games=3072, warmup=3, steps=5, eval_cache=24),
             )
             out["other_configs"] = []
-            for leg in legs:
-                beat("leg %s ..." % leg["name"])
+            for leg, (lname, lsec) in zip(legs, LEG_SECONDS):
+                assert leg["name"] == lname
+                rate_seen = max(out["value"], 1.0)
+                need = 1.5 * lsec * MEASURED_RATE / rate_seen
+                if time.time() - t_start + need > LEGS_HARD_STOP:
+                    out["other_configs"].append({"config": lname, "skipped": "the run was %.0f s old and the leg is planned at %.0f s: "
+                                                 "it would not end before %.0f s" % (time.time() - t_start, need / 1.5, LEGS_HARD_STOP)})
+                    continue
+                beat("leg %s ..." % lname)
                 try:
                     out["other_configs"].append(run_leg(pkg, torch, **leg))
-                    beat("leg %s: %.1f games/s, frac %.3f, %.0f s" % (leg["name"], out["other_configs"][-1]["value"],
+                    beat("leg %s: %.1f games/s, frac %.3f, %.0f s" % (lname, out["other_configs"][-1]["value"],
                                                                       out["other_configs"][-1]["roofline_frac"],
                                                                       out["other_configs"][-1]["leg_seconds"]))
                 except Exception as exc:   # a failing leg must not take the headline down with it
-                    out["other_configs"].append({"config": leg["name"], "error": repr(exc)})
+                    out["other_configs"].append({"config": lname, "error": repr(exc)})
             print("[bench partial] " + json.dumps(out), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1 and args.board == 8:   # the oracle's CPU network is 8x8 only
             try:
                 out["cpu_baseline"] = cpu_baseline(net, args.sims, args.cpu_budget, evals_per_game)
             except Exception as exc:   # the GPU result must still be reported
                 out["cpu_baseline"] = {"error": repr(exc)}
+        if out.get("other_configs"):
+            # the driver keeps the last 2 000 characters of stdout: the secondary legs once more, compact, as the LAST key
+            # ([games/s, roofline frac, trunk share of the step] per configuration; details in `other_configs`)
+            short = {"configs[3]": "configs[3]", "configs[4]": "configs[4]", "configs[1] + eval cache": "configs[1]+cache"}
+            out["other_configs_summary"] = {
+                short.get(o["config"], o["config"]): ([o["value"], o["roofline_frac"], o["net_time_share"]] if "value" in o
+                                                      else ("skipped" if "skipped" in o else "error"))
+                for o in out["other_configs"]}
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()

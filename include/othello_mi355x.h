@@ -278,6 +278,13 @@ int oth_engine_restore(oth_engine *e, void *stream);
 /* counters of the last run: [0] network evaluations, [1] simulations, [2] plies, [3] games,
  * [4] network batches launched, [5] terminal-leaf simulations, [6] evaluation-cache hits */
 int oth_engine_counters(oth_engine *e, int64_t out[8]);
+/* Statistics of the optional evaluation cache since the run / stream began (no reference counterpart: mcts.py:71 and
+ * parallel_self_play.py:106 build a fresh tree per search and evaluate every position again -- the redundancy the cache
+ * removes): out[0] distinct positions evaluated (first evaluation since the cache was last cleared: compulsory misses),
+ * out[1] repeated evaluations (the position had been evaluated since the clear: its entry was replaced in between, or it
+ * missed twice in one launch), out[2] inserts that replaced a live entry of ANOTHER position (conflict evictions),
+ * out[3] entries of the table (0: no cache).  out[0] + out[1] = network evaluations.  Synchronises `stream`. */
+int oth_engine_cache_stats(oth_engine *e, int64_t out[4], void *stream);
 /* timing hook for bench.py: HIP-event time (ms) spent in the network kernel during the last run, and
  * the number of launches; measured on the stream the kernels ran on */
 int oth_engine_kernel_time(oth_engine *e, double *net_ms, int64_t *net_launches, double *tree_ms, int64_t *tree_launches);

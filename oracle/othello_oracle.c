@@ -1108,4 +1108,79 @@ int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg,
     if (games_ended) *games_ended = ended;
     return total;
 }
+/* Time-bounded form of the phase-uniform baseline (round 5: every hardware thread, a per-stream spread): `streams` serial
+ * self-play streams on `threads` OpenMP threads (0: the runtime's default), stream s starting (s * spread) / streams random
+ * plies into a game; each stream plays whole plies (self_play.py:80-117) until `budget_s` seconds have passed since the
+ * parallel region began AND it has played at least `min_plies`.  plies_out[s] / secs_out[s] (either may be NULL): what
+ * stream s played and how long its timed plies took (its own clock, the random prefix excluded).  Returns total plies. */
+int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
+                               double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
+                               int64_t *n_evals, int *threads_used, int64_t *games_ended) {
+    int64_t total = 0, evals = 0, ended = 0;
+    int nt = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    const double t_begin = omp_get_wtime();
+#else
+    const double t_begin = 0.0;
+#endif
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nt = omp_get_num_threads();
+#endif
+#pragma omp for schedule(dynamic, 1) reduction(+ : total, evals, ended)
+        for (int s = 0; s < streams; ++s) {
+            xo_state st;
+            orc_rng r;
+            default_rng(&r, &st, seed + 1000003ULL * (uint64_t)s);
+            count_ctx cc = {net, 0};
+            orc_board b;
+            orc_reset(&b);
+            int skip = spread > 0 ? (int)(((int64_t)s * spread) / streams) : 0;
+            for (int i = 0; i < skip && !orc_is_terminal(&b); ++i) {
+                int mv[65];
+                int n = orc_legal_list(&b, mv);
+                orc_make_move(&b, mv[(int)(xo_uniform(&st) * n) % n]);
+            }
+            float pi[65];
+            int done = 0;
+#ifdef _OPENMP
+            const double t0 = omp_get_wtime();
+#endif
+            for (;;) {
+#ifdef _OPENMP
+                if (done >= min_plies && omp_get_wtime() - t_begin >= budget_s) break;
+#else
+                if (done >= min_plies) break;
+#endif
+                if (orc_is_terminal(&b)) {
+                    orc_reset(&b);
+                    ended += 1;
+                    continue;
+                }
+                double temp = b.move_count < cfg->temperature_threshold ? 1.0 : 0.0;
+                orc_search_cfg sc = {cfg->num_simulations, cfg->c_puct, cfg->dirichlet_alpha, cfg->dirichlet_epsilon,
+                                     temp, cfg->add_noise};
+                orc_search(&b, &sc, counting_eval, &cc, &r, pi, NULL, NULL, NULL);
+                int a = temp == 0 ? argmax65(pi) : r.choice(r.ctx, pi);
+                orc_make_move(&b, a);
+                ++done;
+                ++total;
+            }
+            if (plies_out) plies_out[s] = done;
+#ifdef _OPENMP
+            if (secs_out) secs_out[s] = omp_get_wtime() - t0;
+#else
+            if (secs_out) secs_out[s] = 0.0;
+#endif
+            evals += cc.evals;
+        }
+    }
+    if (n_evals) *n_evals = evals;
+    if (threads_used) *threads_used = nt;
+    if (games_ended) *games_ended = ended;
+    return total;
+}
 #endif /* ORC_N == 8 */

@@ -102,6 +102,7 @@ _SIGS = {
     "oth_engine_snapshot": (C.c_int, [vp, vp]),
     "oth_engine_restore": (C.c_int, [vp, vp]),
     "oth_engine_counters": (C.c_int, [vp, i64p]),
+    "oth_engine_cache_stats": (C.c_int, [vp, i64p, vp]),
     "oth_engine_kernel_time": (C.c_int, [vp, f64p, i64p, f64p, i64p]),
     "oth_engine_set_timing": (C.c_int, [vp, C.c_int32]),
     "oth_engine_net_spans": (C.c_int, [vp, f64p, C.c_int64, i64p]),

@@ -87,6 +87,11 @@ struct Dev {  // device pointers + scalars handed to every kernel by value
     float* cres;        // [n_slots][66] result row copied at lookup time (an insert may replace the entry later)
     uint32_t cmask;     // C - 1, 0 = cache disabled
     int32_t cepoch;
+    // cache statistics (oth_engine_cache_stats): a bitmap of 64 bits per entry over a second hash of the position -- "has
+    // this position been evaluated since the cache was cleared?" -- splits the misses into first evaluations (compulsory)
+    // and repeats (the entry was replaced in between, or the same position missed twice in one launch); per-block rows
+    unsigned long long* cseen;       // [C] words of 64 bits
+    unsigned long long* cstat;       // [blocks][4]: distinct positions, repeated evaluations, conflict evictions, -
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------
@@ -269,7 +274,24 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
     const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g];
     const uint32_t cs = cache_slot(d, sb, ob);
     int own = 0;
-    if (lane == 0) own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
+    if (lane == 0) {
+        // statistics: first evaluation of this position since the clear, or a repeat?  (second hash: the slot hash's
+        // finaliser run once more over the swapped pair; 64 bits per entry, so false "seen" stays below ~1 %)
+        uint64_t h = sb * 0x9E3779B97F4A7C15ULL ^ (ob + 0xD1B54A32D192ED03ULL);
+        h = (h ^ (h >> 32)) * 0xD6E8FEB86659FD93ULL;
+        h = (h ^ (h >> 32)) * 0xD6E8FEB86659FD93ULL;
+        h ^= h >> 32;
+        const uint64_t bit = h & (((uint64_t)d.cmask + 1) * 64 - 1);
+        const unsigned long long m = 1ULL << (bit & 63);
+        const bool seen = atomicOr(&d.cseen[bit >> 6], m) & m;
+        unsigned long long* st = d.cstat + (size_t)blockIdx.x * 4;
+        atomicAdd(&st[seen ? 1 : 0], 1ULL);
+        own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
+        if (own) {
+            const uint64_t k0 = d.ck[2 * (size_t)cs], k1 = d.ck[2 * (size_t)cs + 1];
+            if (!(k0 == ~0ULL && k1 == ~0ULL) && !(k0 == sb && k1 == ob)) atomicAdd(&st[2], 1ULL);   // a live entry of another position goes
+        }
+    }
     if (!__shfl(own, 0)) return;
     float* dst = d.cv + (size_t)cs * 66;
     if (lane < CELLS) dst[lane] = policy[(size_t)slot * NP + lane];
@@ -862,6 +884,7 @@ static int cache_clear(oth_engine* e, hipStream_t s) {
     const size_t C = (size_t)e->d.cmask + 1;
     OTH_HIP(hipMemsetAsync(e->d.ck, 0xFF, C * 2 * sizeof(uint64_t), s));
     OTH_HIP(hipMemsetAsync(e->d.clk, 0, C * sizeof(int32_t), s));
+    OTH_HIP(hipMemsetAsync(e->d.cseen, 0, C * sizeof(unsigned long long), s));   // (the statistics rows are cumulative)
     e->d.cepoch = 0;
     return OTH_OK;
 }
@@ -987,6 +1010,7 @@ static int reset_run(oth_engine* e, int hist_games, int game_limit, int n_start,
     if (r) return r;
     OTH_HIP(hipMemsetAsync(e->d.game_len, 0xFF, sizeof(int32_t) * (size_t)e->hist_cap, s));  // -1: free
     OTH_HIP(hipMemsetAsync(e->d.counters, 0, sizeof(unsigned long long) * 8 * (size_t)blocks_for(e->d.n_slots), s));
+    if (e->d.cmask) OTH_HIP(hipMemsetAsync(e->d.cstat, 0, sizeof(unsigned long long) * 4 * (size_t)blocks_for(e->d.n_slots), s));
     const int32_t st[4] = {0, 0, 0, n_start};
     OTH_HIP(hipMemcpyAsync(e->d.status, st, sizeof(st), hipMemcpyHostToDevice, s));
     OTH_HIP(hipStreamSynchronize(s));  // `st` lives on this stack frame
@@ -1091,6 +1115,8 @@ oth_engine* oth_engine_create(const oth_engine_cfg* cfg) {
         r |= dev_alloc(e, &d.cv, C * 66);
         r |= dev_alloc(e, &d.clk, C);
         r |= dev_alloc(e, &d.cres, (size_t)G * 66);
+        r |= dev_alloc(e, &d.cseen, C);
+        r |= dev_alloc(e, &d.cstat, (size_t)blocks_for(G) * 4);
         if (!r) {
             d.cmask = (uint32_t)(C - 1);
             if (hipMemset(d.ck, 0xFF, C * 2 * sizeof(uint64_t)) != hipSuccess) r = 1;
@@ -1435,7 +1461,7 @@ int oth_engine_snapshot(oth_engine* e, void* stream) {
         sn.copies.clear();
         sn.regions.clear();
         const Dev& d = e->d;
-        const void* skip[] = {d.nodes, d.edges, d.path, d.ck, d.cv, d.clk, d.sqrt_tab, e->r_pi, e->r_prior, e->r_visits,
+        const void* skip[] = {d.nodes, d.edges, d.path, d.ck, d.cv, d.clk, d.cseen, d.sqrt_tab, e->r_pi, e->r_prior, e->r_visits,
                               e->r_wsum, e->r_act, e->d_total};
         for (size_t i = 0; i < e->allocs.size(); ++i) {
             bool sk = false;
@@ -1533,6 +1559,23 @@ int oth_selfplay_device_ptrs(oth_engine* e, float** states, float** pis, float**
 int oth_engine_counters(oth_engine* e, int64_t out[8]) {
     OTH_CHECK(e && out, "oth_engine_counters: null argument");
     for (int i = 0; i < 8; ++i) out[i] = e->counters[i];
+    return OTH_OK;
+}
+
+int oth_engine_cache_stats(oth_engine* e, int64_t out[4], void* stream) {
+    OTH_NEED_DEVICE();
+    OTH_CHECK(e && out, "oth_engine_cache_stats: null argument");
+    out[0] = out[1] = out[2] = 0;
+    out[3] = e->d.cmask ? (int64_t)e->d.cmask + 1 : 0;
+    if (!e->d.cmask) return OTH_OK;
+    OTH_BIND(e->device);
+    hipStream_t s = as_stream(stream);
+    const size_t nb = (size_t)blocks_for(e->d.n_slots);
+    std::vector<unsigned long long> h(nb * 4);
+    OTH_HIP(hipMemcpyAsync(h.data(), e->d.cstat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OTH_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < nb; ++b)
+        for (int i = 0; i < 3; ++i) out[i] += (int64_t)h[b * 4 + i];
     return OTH_OK;
 }
 

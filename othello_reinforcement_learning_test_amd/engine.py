@@ -432,6 +432,14 @@ class SearchEngine:
         keys = ("evals", "simulations", "plies", "games", "net_batches", "terminal_sims", "cache_hits")
         return dict(zip(keys, list(out)[:7]))
 
+    def cache_stats(self):
+        """Evaluation-cache statistics since the run / stream began: distinct positions evaluated (compulsory misses),
+        repeated evaluations (the entry was replaced in between, or a double miss in one launch), conflict evictions,
+        entries of the table."""
+        out = (C.c_int64 * 4)()
+        _lib.call("oth_engine_cache_stats", self._h, out, _lib.current_stream())
+        return dict(zip(("distinct_positions", "repeated_evals", "conflict_evictions", "entries"), list(out)))
+
     def set_timing(self, enable=True):
         _lib.call("oth_engine_set_timing", self._h, 1 if enable else 0)
 

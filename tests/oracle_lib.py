@@ -119,6 +119,10 @@ def lib():
         L.orc_cpu_baseline.restype = C.c_int64
         L.orc_cpu_baseline.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int,
                                        C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_cpu_baseline_timed.restype = C.c_int64
+        L.orc_cpu_baseline_timed.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                             C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.orc_cpu_baseline_spread.restype = C.c_int64
         L.orc_cpu_baseline_spread.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int, C.c_int,
                                               C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int),

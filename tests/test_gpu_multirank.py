@@ -104,3 +104,5 @@ def test_bench_other_configs_leg_small():
                       warmup=1, steps=2, eval_cache=12, c_puct=1.5, temp_threshold=20, stagger=8)
     assert b["value"] > 0 and b["kernel"].startswith("k_trunk_f32") and b["eval_cache"]["hits"] > 0
     assert 0 < b["eval_cache"]["hit_rate"] < 1 and "c_puct 1.50" in b["workload"] and "threshold 20" in b["workload"]
+    ec = b["eval_cache"]   # the misses split into first evaluations and repeats; evictions counted
+    assert ec["compulsory_misses"] > 0 and ec["compulsory_misses"] + ec["repeat_misses"] > 0 and ec["conflict_evictions"] >= 0

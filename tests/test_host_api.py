@@ -204,14 +204,24 @@ def test_no_mfma_hazards_in_built_objects():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     objs = [os.path.join(root, "othello_reinforcement_learning_test_amd", "csrc", f)
             for f in ("net_mfma.o", "net_h3.o", "net_wino.o", "net_wino6.o", "net_f32.o")]
-    if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
-        pytest.skip("object files / llvm-objdump not present (the .o files do not travel to the GPU box)")
     spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("object files not present (the .o files do not travel to the GPU box)")
+    try:
+        mod.find_objdump()          # $ROCM_PATH / $HIP_PATH / /opt/rocm / PATH (not one hard-coded place)
+    except SystemExit:
+        pytest.skip("llvm-objdump not found")
+    forms = {}
     for o in objs:
-        n, bad = mod.check_object(o)
+        n, bad, _, _ = mod.check_text(mod.disassemble(o), forms)
         assert n > 200 and not bad, bad[:3]
+    # rule 3's inventory: the only operand-select forms that ship are the epilogue's v_fma_mixlo / mixhi_f16 (probed clean
+    # beside an MFMA partner, profiles/r05_probe_pk_opsel.txt); packed fp32 ships on plain pairs only
+    sel = sorted(k for k in forms if "op_sel" in k)
+    assert sel == ["v_fma_mixhi_f16 op_sel:[1,0,0]"], sel
+    assert forms.get("v_fma_mixlo_f16", 0) == forms["v_fma_mixhi_f16 op_sel:[1,0,0]"] > 0
 
 
 def test_hazard_checker_sees_across_branch_edges():
@@ -272,7 +282,16 @@ def test_hazard_checker_sees_across_branch_edges():
     pk = lambda sel: asm([("v_pk_fma_f32", "v[4:5], v[22:23], v[14:15], v[4:5] " + sel)])   # noqa: E731
     assert len(mod.check_text(pk("op_sel:[0,1,0]"))[1]) == 1
     assert mod.check_text(pk("op_sel_hi:[1,0,1]"))[1] == [] and mod.check_text(pk(""))[1] == []
-    assert mod.check_text(asm([("v_pk_fma_f16", "v4, v22, v14, v4 op_sel:[0,1,0]")]))[1] == []   # 16-bit packed ops: not meant
+    assert mod.check_text(asm([("v_pk_fma_f16", "v4, v22, v14, v4 op_sel:[0,1,0]")]))[1] == []   # 16-bit packed ops: probed clean (r5)
+    # round 5's probe: v_pk_mul / v_pk_add with source 1's high dword fail like the FMA; the rule also keeps the source-0 /
+    # source-2 routes out (clean in one run -- not shipped unseen); v_pk_mov_b32 was probed clean and is only counted
+    for mn, ops in (("v_pk_mul_f32", "v[4:5], v[22:23], v[14:15] op_sel:[0,1]"), ("v_pk_add_f32", "v[4:5], v[22:23], v[14:15] op_sel:[0,1]"),
+                    ("v_pk_fma_f32", "v[4:5], v[22:23], v[14:15], v[4:5] op_sel:[1,0,0]")):
+        assert len(mod.check_text(asm([(mn, ops)]))[1]) == 1, mn
+    forms = {}
+    assert mod.check_text(asm([("v_pk_mov_b32", "v[4:5], v[22:23], v[14:15] op_sel:[1,0]"),
+                               ("v_pk_add_f32", "v[4:5], v[22:23], v[14:15] neg_lo:[0,1] neg_hi:[0,1]")]), forms)[1] == []
+    assert forms == {"v_pk_mov_b32 op_sel:[1,0]": 1, "v_pk_add_f32 neg": 1}
     # (5) AGPR operands: v_accvgpr_write of an MFMA's A operand right in front of it; an AGPR result read too early
     amf = ("v_mfma_f32_16x16x32_f16", "v[0:3], a[16:19], v[12:15], v[0:3]")
     assert len(mod.check_text(asm([("v_accvgpr_write_b32", "a17, v40"), amf]))[1]) == 1

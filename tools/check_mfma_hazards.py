@@ -168,11 +168,22 @@ def hazards(seq, first_consumer, last_producer):
     return bad
 
 
-PK_F32 = re.compile(r"^v_pk_(fma|mul|add)_f32$|^v_pk_mov_b32$")
+# Rule (3).  Probed on the GPU beside an MFMA-issuing wave of the same SIMD (tools/probes/probe_pk_opsel.hip, round 4;
+# tools/probes/probe_pk_opsel2.hip, round 5: profiles/r05_probe_pk_opsel.txt):
+#   UNRELIABLE  v_pk_fma_f32 op_sel:[0,1,0], v_pk_mul_f32 op_sel:[0,1], v_pk_add_f32 op_sel:[0,1] -- SOURCE 1's high dword
+#               routed to the low lane (37-47 % of wave-results wrong; 0 without an MFMA partner);
+#   clean       v_pk_fma_f32 op_sel:[1,0,0] / [0,0,1] (source 0 / 2 high -> low), op_sel_hi:[0,1,1] / [1,0,1] (low -> high),
+#               v_pk_mov_b32 op_sel:[1,0], v_pk_fma/mul/add_f16 with op_sel, v_fma_mixlo/mixhi_f16 with op_sel (the shipped
+#               epilogue's form), packed fp32 with neg_lo / neg_hi on plain pairs (shipped).
+# The rule stays wider than the defect: ANY high-to-low select on a packed-fp32 arithmetic instruction fails the build (the
+# source-0 / source-2 routes were clean in one run of one instruction, v_pk_fma_f32 -- not enough to ship them unseen); the
+# forms shown clean are counted per object so that what ships is known, not assumed (packed_forms below).
+PK_F32 = re.compile(r"^v_pk_(fma|mul|add)_f32$")
+PK_ANY = re.compile(r"^v_pk_\w+$|^v_fma_mix(lo|hi)?_f16$|^v_fma_mix_f32$")
 
 
 def pk_opsel_hi_to_lo(fn):
-    """Rule (3): packed-fp32 instructions whose op_sel routes a source's high dword to the low lane."""
+    """Rule (3): packed-fp32 arithmetic whose op_sel routes a source's high dword to the low lane."""
     bad = []
     for x in fn:
         if PK_F32.match(x.mn):
@@ -183,11 +194,30 @@ def pk_opsel_hi_to_lo(fn):
     return bad
 
 
-def check_text(text):
+def packed_forms(fn, counts):
+    """Count every packed / mixed-precision VALU form of a function by mnemonic and modifier class."""
+    for x in fn:
+        if not PK_ANY.match(x.mn):
+            continue
+        m = re.search(r"op_sel:\[([01,]+)\]", x.ops)
+        h = re.search(r"op_sel_hi:\[([01,]+)\]", x.ops)
+        key = x.mn
+        if m and "1" in m.group(1):
+            key += " op_sel:[%s]" % m.group(1)
+        if h and "0" in h.group(1) and not x.mn.startswith("v_fma_mix"):   # (mix ops: op_sel_hi = "this source is f16")
+            key += " op_sel_hi:[%s]" % h.group(1)
+        if "neg_lo" in x.ops or "neg_hi" in x.ops:
+            key += " neg"
+        counts[key] = counts.get(key, 0) + 1
+
+
+def check_text(text, forms=None):
     """-> (number of MFMAs, hazard messages, number of branch edges checked, indirect jumps seen)"""
     n_mfma, bad, edges, indirect = 0, [], 0, 0
     for fn in parse(text):
         bad += pk_opsel_hi_to_lo(fn)
+        if forms is not None:
+            packed_forms(fn, forms)
         n_mfma += sum(1 for x in fn if x.is_mfma)
         indirect += sum(1 for x in fn if x.mn.startswith("s_setpc") or x.mn.startswith("s_swappc"))
         bad += hazards(fn, 0, None)                      # straight-line code incl. every fall-through edge
@@ -216,9 +246,9 @@ def check_object(path):
 
 
 def main(paths):
-    total, failed = 0, []
+    total, failed, forms = 0, [], {}
     for p in paths:
-        n, bad, edges, indirect = check_text(disassemble(p))
+        n, bad, edges, indirect = check_text(disassemble(p), forms)
         total += n
         failed += bad
         print("%s: %d MFMA instructions, %d branch edges, %d hazards%s"
@@ -231,6 +261,11 @@ def main(paths):
         print("  %4d in %s" % (v, k))
     for b in failed[:6]:
         print("  HAZARD " + b)
+    # what ships: every packed / mixed-precision VALU form of the built objects (rule 3's comment says which were probed)
+    sel = {k: v for k, v in forms.items() if "op_sel" in k or k.startswith("v_fma_mix")}
+    plain = {k: v for k, v in forms.items() if k not in sel}
+    print("packed forms in the built objects: " + (", ".join("%s x%d" % kv for kv in sorted(plain.items())) or "none"))
+    print("  with an operand select: " + (", ".join("%s x%d" % kv for kv in sorted(sel.items())) or "none"))
     return 1 if failed else 0
 
 

@@ -60,6 +60,31 @@ ABLATIONS = {
         ("net_wino6.hip", "                if (step < 8) wq[(grp + 1) & 1][step] = wl[(size_t)(grp + 1) * k6GroupU4 + (size_t)step * 64];",
          '                if (step < 8) asm volatile("" : "+v"(wq[(grp + 1) & 1][step]));'),
     ]),
+    # ---- k_trunk_w6 experiment (b) of round 5 (CORRECT results): VERDICT r4 item 4b -- read the finished accumulators into
+    #      VGPR copies BETWEEN the last group's MFMAs (each three steps after its last MFMA) instead of after the convolution.
+    #      ISA of the build: the allocator has no room for 144 more live VGPRs and parks the copies back in AGPRs (80
+    #      v_accvgpr_write + 68 v_mov in the convolution, the epilogue's reads stay): more VALU, not less.
+    "w6_exp_early_acc_reads": ("finished accumulators read between the last group's MFMAs (correct results; measured slower)", [
+        ("net_wino6.hip", "    f32x4 res[k6NT][2];   // [N-tile][x parity]: the residual in the spatial domain, fp32, x act_scale\n",
+         "    f32x4 res[k6NT][2];   // [N-tile][x parity]: the residual in the spatial domain, fp32, x act_scale\n"
+         "    f32x4 accv[4][k6NT];  // VGPR copies of the finished accumulators\n"),
+        ("net_wino6.hip", "                        const f32x2 a0 = whalf(acc[0][nt], h), a1 = whalf(acc[1][nt], h), a2 = whalf(acc[2][nt], h),\n"
+                          "                                    a3 = whalf(acc[3][nt], h);",
+         "                        const f32x2 a0 = whalf(accv[0][nt], h), a1 = whalf(accv[1][nt], h), a2 = whalf(accv[2][nt], h),\n"
+         "                                    a3 = whalf(accv[3][nt], h);"),
+        ("net_wino6.hip", "    // V addressing (see the header): run (j, xi, k-step, half)",
+         "#pragma unroll\n    for (int xi = 0; xi < 4; ++xi)\n#pragma unroll\n        for (int nt = 0; nt < k6NT; ++nt) accv[xi][nt] = acc[xi][nt];\n"
+         "    // V addressing (see the header): run (j, xi, k-step, half)"),
+        ("net_wino6.hip", "                acc[xi][nt] = w6mfma(wlo, xh[sl], acc[xi][nt]);\n                OTH_W6SB;\n            }\n        };",
+         "                acc[xi][nt] = w6mfma(wlo, xh[sl], acc[xi][nt]);\n                OTH_W6SB;\n"
+         "                if (grp == k6Groups - 1 && step >= 3) {\n                    const int s2 = step - 3;\n"
+         "                    f32x4 tcopy = acc[s2 & 3][s2 >> 2];\n                    asm volatile(\"\" : \"+v\"(tcopy));\n"
+         "                    accv[s2 & 3][s2 >> 2] = tcopy;\n                    OTH_W6SB;\n                }\n            }\n        };"),
+        ("net_wino6.hip", "        conv_d(std::integral_constant<int, 2>{});\n    }\n",
+         "        conv_d(std::integral_constant<int, 2>{});\n#pragma unroll\n        for (int s2 = GS - 3; s2 < GS; ++s2) {\n"
+         "            f32x4 tcopy = acc[s2 & 3][s2 >> 2];\n            asm volatile(\"\" : \"+v\"(tcopy));\n"
+         "            accv[s2 & 3][s2 >> 2] = tcopy;\n        }\n    }\n"),
+    ]),
 }
 
 
