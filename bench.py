@@ -811,6 +811,9 @@ def main():
             # beside a trunk launch of ~1.4 ms, so with two lanes there are moments when both are in it (trunk share of the
             # step 0.94-0.97, 76.7-77.3 games/s at 4096-4416 slots); the third lane keeps a trunk launch running (0.996;
             # profiles/r05_sweep_configs3.txt: 80.2 games/s, the same as 6624 slots in three lanes at a shorter ramp).
+            # configs[4]: 8960 slots in FOUR lanes of 2240 -- k_trunk_w6 fills a CU with one workgroup, so the tree kernels of the
+            # other lanes run in its shadow; a lane's launch is ~1 990 positions = 249 of 256 workgroups (2048 slots: 228), and
+            # the fourth lane keeps a trunk launch running (trunk share 0.964 -> 0.978, +3.4 %: profiles/r05_sweep_configs4_b.txt).
             # configs[1] + cache: 8192 slots in two lanes and steps of 3072 games (the same slots : step ratio as the
             # headline, so a game sees as many cache clears), so that a launch of the MISSES is again ~1 350 positions
             # (profiles/r05_sweep_cache.txt: 1 663 vs 1 498 games/s at 4096 slots), and 2^24 entries per lane (4.9 GB of the
@@ -819,7 +822,7 @@ def main():
                 dict(name="configs[3]", board=8, blocks=10, filters=128, sims=400, games=4608, lanes=3, step_games=255, warmup=2, steps=4,
                      c_puct=1.5, temp_threshold=20),
                 dict(name="configs[4]", note="6x6 RULES PARITY UNPINNED (the reference implements no 6x6 game)",
-                     board=6, blocks=5, filters=64, sims=25, games=6144, lanes=3, step_games=32769, warmup=3, steps=4),
+                     board=6, blocks=5, filters=64, sims=25, games=8960, lanes=4, step_games=32768, warmup=3, steps=4),
                 dict(name="configs[1] + eval cache", note="evaluation cache ON: NOT the headline configuration, never `value`",
                      board=8, blocks=10, filters=128, sims=50, games=8192, step_games=3072, warmup=3, steps=5, eval_cache=24),
             )

@@ -186,13 +186,15 @@ def policy_from_visits(visits, self_b, opp_b, temperature, board_size=8):
     A TERMINAL root is not node.py:164's childless case: get_legal_moves() returns [64] there (bitboard.pyx:177-185), the
     root is expanded with the pass child and every simulation is backed up through it, so the policy is one-hot on the
     pass at every temperature (fixture g9, generated by the reference).  Only a search of zero simulations has all-zero
-    counts, and there the reference itself evaluates 0/0; this mirror then returns the zero vector instead of NaN."""
+    counts: at T = 0 the reference then returns the one-hot on actions[argmax(zeros)] = the FIRST child (node.py:170-173)
+    and so does this mirror; at T != 0 the reference evaluates 0/0 and this mirror returns the zero vector instead of NaN
+    (a deliberate deviation; parity unpinned: no fixture has zero simulations)."""
     npol = board_size * board_size + 1
     policy = np.zeros(npol, dtype=np.float32)
     legal = int(_lib.load().oth_legal_moves_n(board_size, self_b, opp_b))
     actions = [a for a in range(npol - 1) if (legal >> a) & 1] or [npol - 1]
     counts = np.array([visits[a] for a in actions], dtype=np.float32)
-    if not counts.any():
+    if temperature != 0 and not counts.any():
         return policy
     if temperature == 0:
         policy[actions[int(np.argmax(counts))]] = 1.0

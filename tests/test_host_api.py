@@ -299,3 +299,23 @@ def test_hazard_checker_sees_across_branch_edges():
     assert mod.check_text(asm([("v_accvgpr_write_b32", "a21, v40"), amf]))[1] == []           # another register
     agm = ("v_mfma_f32_16x16x32_f16", "a[0:3], v[8:11], v[12:15], a[0:3]")
     assert len(mod.check_text(asm([agm, ("v_accvgpr_read_b32", "v9, a2")]))[1]) == 1
+
+
+def test_zero_simulation_policy_and_force_dist_parsing(monkeypatch):
+    """Two small host-side behaviours.  (1) node.py:162-182 with an expanded but unvisited root: at T = 0 the
+    reference returns the one-hot on actions[argmax(zeros)] = the FIRST child; at T != 0 it evaluates 0/0, where this mirror
+    returns zeros (documented deviation, parity unpinned).  (2) OTHELLO_FORCE_DIST=0 / false means OFF."""
+    import numpy as np
+    from othello_reinforcement_learning_test_amd import distributed as D
+    from othello_reinforcement_learning_test_amd.engine import policy_from_visits
+    from othello_reinforcement_learning_test_amd.bitboard import OthelloBitboard
+    b = OthelloBitboard()
+    zero = np.zeros(65, dtype=np.int32)
+    p0 = policy_from_visits(zero, b.self_board, b.opp_board, 0.0)
+    assert p0.sum() == 1.0 and p0[b.get_legal_moves()[0]] == 1.0
+    assert not policy_from_visits(zero, b.self_board, b.opp_board, 1.0).any()
+    for val, want in (("0", False), ("false", False), ("", False), ("off", False), ("1", True), ("yes", True)):
+        monkeypatch.setenv("OTHELLO_FORCE_DIST", val)
+        assert D.force_dist_from_env() is want, val
+    monkeypatch.delenv("OTHELLO_FORCE_DIST")
+    assert D.force_dist_from_env() is False

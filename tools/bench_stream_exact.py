@@ -5,7 +5,8 @@ id (oracle driven by the HIP network's own outputs), and each step's set of game
 streaming schedule computed from the oracle's game lengths.
 usage (GPU box, repo root): python tools/bench_stream_exact.py [steps] [step_games]   -> profiles/rNN_bench_stream_exact.log
 OTH_EXACT_CACHE=22 runs the engines with the opt-in evaluation cache (2^22 entries per lane): the tuples must STILL be identical
-(a hit returns the bits an evaluation would have produced); the hit count is printed."""
+(a hit returns the bits an evaluation would have produced); the hit count is printed.  OTH_EXACT_SLOTS=8192 (with
+OTH_EXACT_CACHE=24 and `2 3072` as arguments): the shape of bench.py's evaluation-cache leg since round 5."""
 import os
 import sys
 import time
@@ -22,7 +23,7 @@ from test_gpu_selfplay_exact import simulate_stream      # noqa: E402  (the sche
 cache_log2 = int(os.environ.get("OTH_EXACT_CACHE", "0"))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 step_games = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
-lanes, slots, sims, thr, stagger, rank = 2, 4096, 50, 15, 61, 0
+lanes, slots, sims, thr, stagger, rank = 2, int(os.environ.get("OTH_EXACT_SLOTS", "4096")), 50, 15, 61, 0
 per = slots // lanes
 U64 = np.uint64
 torch.manual_seed(42)

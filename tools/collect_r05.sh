@@ -26,9 +26,9 @@ nets)
   OTH_WINO=0 python3 tools/netbench.py --nets 10x128x8:f16x3 2>&1 | grep -v amdgpu | sed "s/$/   [OTH_WINO=0: direct kernel k_trunk16]/" >> $O/netbench.log
   OTH_WINO6=0 python3 tools/netbench.py --nets 5x64x6:f16x3 2>&1 | grep -v amdgpu | sed "s/$/   [OTH_WINO6=0: direct kernel k_trunk_h3]/" >> $O/netbench.log ;;
 cache)    # configs[1] with the opt-in evaluation cache, the driver's steps / warm-up: a labelled secondary figure, never the headline
-  python3 bench.py --gpus 1 --steps 20 --warmup 5 --eval-cache 22 --no-cpu-baseline --no-other-configs > $O/bench_eval_cache22.json 2> $O/bench_eval_cache22.stderr.txt || exit 1
-  python3 tools/print_bench_lines.py $O/bench_eval_cache22.json ;;
+  python3 bench.py --gpus 1 --steps 10 --warmup 3 --games 8192 --step-games 3072 --eval-cache 24 --no-cpu-baseline --no-other-configs > $O/bench_eval_cache24.json 2> $O/bench_eval_cache24.stderr.txt || exit 1
+  python3 tools/print_bench_lines.py $O/bench_eval_cache24.json ;;
 exact)
   python3 tools/bench_stream_exact.py > $O/bench_stream_exact.log 2>&1 || exit 1; tail -1 $O/bench_stream_exact.log
-  OTH_EXACT_CACHE=22 python3 tools/bench_stream_exact.py > $O/bench_stream_exact_cache22.log 2>&1 || exit 1; tail -1 $O/bench_stream_exact_cache22.log ;;
+  OTH_EXACT_CACHE=24 OTH_EXACT_SLOTS=8192 python3 tools/bench_stream_exact.py 2 3072 > $O/bench_stream_exact_cache24.log 2>&1 || exit 1; tail -1 $O/bench_stream_exact_cache24.log ;;
 esac; done

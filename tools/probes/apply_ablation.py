@@ -85,6 +85,25 @@ ABLATIONS = {
          "            f32x4 tcopy = acc[s2 & 3][s2 >> 2];\n            asm volatile(\"\" : \"+v\"(tcopy));\n"
          "            accv[s2 & 3][s2 >> 2] = tcopy;\n        }\n    }\n"),
     ]),
+    # ---- k_trunk_w6 experiment (a') of round 5 (CORRECT results, bit-identical): the heads' two FC weight arrays staged through LDS
+    #      once per workgroup instead of six exposed L2 round trips per wave (VERDICT r4 item 4a asked for the heads out of the
+    #      trunk; a head kernel cannot co-reside with a trunk workgroup, so the in-trunk latency is what can be attacked).
+    "w6_exp_fc_lds": ("heads' FC weights through LDS (correct, bit-identical results)", [
+        ("net_wino6.hip", "                for (int r = 0; r < 4; ++r) planes[(ch0 + r) * NCO + ci] = v[r] * us;\n            }\n    __syncthreads();",
+         "                for (int r = 0; r < 4; ++r) planes[(ch0 + r) * NCO + ci] = v[r] * us;\n            }\n"
+         "    constexpr int kFcFloats = 2 * k6Cells * k6NP + k6Cells * 256;          // 2664 + 9216 = 11880 floats = 2970 float4\n"
+         "    constexpr int kFcOff = k6F * NCO * 4 + 4 * 2 * 192 * 4;                 // behind the planes (73 728 B) and the scratch rows\n"
+         "    static_assert(kFcOff + kFcFloats * 4 <= k6Lds && (2 * k6Cells * k6NP) % 4 == 0, \"FC weights must fit behind the planes\");\n"
+         "    float* fc_lds = (float*)(lds + kFcOff);\n"
+         "    {\n        float4 fcw[12];\n#pragma unroll\n        for (int i = 0; i < 12; ++i) {\n"
+         "            const int q = tid + 256 * i;                                   // float4 index: policy FC first, then value FC1\n"
+         "            const float4* src = q < 2 * k6Cells * k6NP / 4 ? (const float4*)a.pfc_wt + q : (const float4*)a.vfc1_wt + (q - 2 * k6Cells * k6NP / 4);\n"
+         "            fcw[i] = q < kFcFloats / 4 ? *src : make_float4(0.f, 0.f, 0.f, 0.f);\n        }\n#pragma unroll\n"
+         "        for (int i = 0; i < 12; ++i)\n            if (tid + 256 * i < kFcFloats / 4) ((float4*)fc_lds)[tid + 256 * i] = fcw[i];\n    }\n"
+         "    __syncthreads();"),
+        ("net_wino6.hip", "heads_wave_n<k6F, k6BS, 2, true>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);",
+         "heads_wave_n<k6F, k6BS, 2, true>(a.heads, fc_lds, fc_lds + 2 * k6Cells * k6NP, srcs, NCO, scratch, lane, lps, vs, live);"),
+    ]),
 }
 
 
