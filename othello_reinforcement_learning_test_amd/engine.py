@@ -116,7 +116,8 @@ class HipResNetEvaluator:
 
     @property
     def act_scale(self):
-        """Power-of-two pre-scale of the activations in the fp16-split trunks (16 by default; 1.0 under 'f32')."""
+        """Power-of-two pre-scale of the activations in the fp16-split trunks (16 by default, lowered by needs_rescue; the
+        exact-fp32 trunk of precision 'f32' does not use it)."""
         s = C.c_float(0)
         _lib.call("oth_net_get_act_scale", self._h, C.byref(s))
         return float(s.value)

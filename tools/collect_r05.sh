@@ -6,6 +6,8 @@ export TMPDIR=/tmp
 O=gpurun_out/r05; mkdir -p $O
 parts=${@:-tests nets}
 for part in $parts; do case $part in
+smoke)    # the driver's smoke entry
+  python3 __graft_entry__.py --smoke > $O/smoke.log 2>&1; rc=$?; tail -2 $O/smoke.log; [ $rc -eq 0 ] || exit $rc ;;
 tests)    # the whole GPU suite, incl. the three child stages (self-launched gloo rehearsal, RCCL one-rank bench and worker)
   python3 -m pytest tests -m gpu -x -q -s > $O/gpu_tests.log 2>&1; rc=$?; echo "pytest rc $rc" >> $O/gpu_tests.log; tail -4 $O/gpu_tests.log
   [ $rc -eq 0 ] || exit $rc ;;
