@@ -487,6 +487,16 @@ def check_world(args, argv):
     return None
 
 
+def summarize_legs(other_configs):
+    """The secondary legs once more, compact: {configuration: [games/s, roofline frac, trunk share of the step]} (or "skipped" /
+    "error").  The driver keeps the last 2 000 characters of stdout, and the full `other_configs` entries are longer than
+    that, so this goes LAST in the JSON line (< 300 characters)."""
+    short = {"configs[1] + eval cache": "configs[1]+cache"}
+    return {short.get(o["config"], o["config"]): ([o["value"], o["roofline_frac"], o["net_time_share"]] if "value" in o
+                                                  else ("skipped" if "skipped" in o else "error"))
+            for o in other_configs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -850,13 +860,7 @@ def main():
             except Exception as exc:   # the GPU result must still be reported
                 out["cpu_baseline"] = {"error": repr(exc)}
         if out.get("other_configs"):
-            # the driver keeps the last 2 000 characters of stdout: the secondary legs once more, compact, as the LAST key
-            # ([games/s, roofline frac, trunk share of the step] per configuration; details in `other_configs`)
-            short = {"configs[3]": "configs[3]", "configs[4]": "configs[4]", "configs[1] + eval cache": "configs[1]+cache"}
-            out["other_configs_summary"] = {
-                short.get(o["config"], o["config"]): ([o["value"], o["roofline_frac"], o["net_time_share"]] if "value" in o
-                                                      else ("skipped" if "skipped" in o else "error"))
-                for o in out["other_configs"]}
+            out["other_configs_summary"] = summarize_legs(out["other_configs"])   # LAST key: survives the driver's tail
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()

@@ -55,3 +55,20 @@ def test_union_ms_and_mflop():
     c = np.array([[1.0, 3.0], [5.5, 5.8], [10.0, 11.0]])
     assert b.union_ms([a, c]) == 3.0 + 1.0 + 1.0
     assert b.union_ms([np.zeros((0, 2))]) == 0.0
+
+
+def test_other_configs_summary_is_compact_and_last():
+    """The driver records the last 2 000 characters of bench.py's stdout: the secondary legs must be readable from there
+    (VERDICT r4 item 3c).  The summary is < 300 characters whatever the legs did, and main() appends it as the last key."""
+    import json
+    b = _bench()
+    legs = [{"config": "configs[3]", "value": 80.37, "roofline_frac": 0.2689, "net_time_share": 0.9963, "note": "x" * 500},
+            {"config": "configs[4]", "skipped": "the run was 500 s old"},
+            {"config": "configs[1] + eval cache", "error": "RuntimeError('boom')"}]
+    s = b.summarize_legs(legs)
+    assert s == {"configs[3]": [80.37, 0.2689, 0.9963], "configs[4]": "skipped", "configs[1]+cache": "error"}
+    full = [dict(config=n, value=27863.57, roofline_frac=0.2221, net_time_share=0.9780) for n, _ in b.LEG_SECONDS]
+    assert len(json.dumps(b.summarize_legs(full))) < 300
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i = src.index('out["other_configs_summary"] = summarize_legs')
+    assert "print(json.dumps(out), flush=True)" in src[i:i + 200]          # nothing is added to the line after it
