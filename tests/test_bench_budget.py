@@ -72,3 +72,31 @@ def test_other_configs_summary_is_compact_and_last():
     src = open(os.path.join(ROOT, "bench.py")).read()
     i = src.index('out["other_configs_summary"] = summarize_legs')
     assert "print(json.dumps(out), flush=True)" in src[i:i + 200]          # nothing is added to the line after it
+
+
+def test_committed_traffic_knows_when_it_is_stale(tmp_path, monkeypatch):
+    """roofline.traffic is a committed PMC figure, not this run's measurement: bench.py says so when the
+    newest profiles/rNN_bench_traffic.json was measured on another kernel or on other trunk sources."""
+    import json
+    b = _bench()
+    ct = b.committed_traffic("k_trunk_w<2> (fused ResNet forward ...)")
+    assert ct["traffic"] > 1e8 and ct["tree_traffic"] > 1e6 and "rocprofv3 --pmc" in ct["basis"]
+    assert ct["stale"] is False, ct["why"]                 # the committed file carries the hash of the current trunk sources
+    assert b.committed_traffic("k_trunk16 (fused ...)")["stale"] is True     # another kernel than the one it was measured on
+    # a file without a hash, or with another one, is stale
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    real = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_traffic.json")))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    csrc = tmp_path / "othello_reinforcement_learning_test_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for f in b.TRUNK_SOURCES:
+        (csrc / f).write_text(open(os.path.join(ROOT, "othello_reinforcement_learning_test_amd", "csrc", f)).read())
+    json.dump(real, open(prof / "r05_bench_traffic.json", "w"))
+    assert b.committed_traffic("k_trunk_w<2>")["stale"] is False
+    (csrc / "net_wino.hip").write_text("// changed\n")
+    r = b.committed_traffic("k_trunk_w<2>")
+    assert r["stale"] is True and "sources changed" in r["why"]
+    real.pop("kernel_source_sha256")
+    json.dump(real, open(prof / "r06_bench_traffic.json", "w"))            # the NEWEST file wins
+    assert "no source hash" in b.committed_traffic("k_trunk_w<2>")["why"]

@@ -937,6 +937,20 @@ def test_eval_cache_is_bit_identical(pkg):
     assert stats[0]["cache_hits"] == 0 and stats[1]["cache_hits"] > 0
     assert stats[1]["evals"] + stats[1]["cache_hits"] == stats[0]["evals"]
     assert stats[1]["evals"] < 0.85 * stats[0]["evals"]
+    # the statistics of the cache (round 5): every network evaluation is either the first one of its position since the
+    # cache was cleared or a repeat; a table far too small for the run (2^10 entries) evicts live entries and re-evaluates
+    # positions it had seen -- and the tuples are STILL identical
+    cs = w.engine.cache_stats()
+    assert cs["entries"] == 1 << 16 and cs["distinct_positions"] + cs["repeated_evals"] == stats[1]["evals"]
+    assert cs["distinct_positions"] > 0 and cs["repeated_evals"] < 0.25 * stats[1]["evals"]
+    w2 = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=20, temperature_threshold=8,
+                                    num_parallel_games=32, verbose=False, eval_cache_log2=10)
+    np.random.seed(5)
+    small = w2.execute_episodes(48)
+    assert all(np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1]) and a_[2] == b_[2] for a_, b_ in zip(outs[0], small))
+    cs2 = w2.engine.cache_stats()
+    assert cs2["entries"] == 1024 and cs2["conflict_evictions"] > 0 and cs2["repeated_evals"] > cs["repeated_evals"]
+    assert cs2["distinct_positions"] + cs2["repeated_evals"] == w2.last_stats["evals"] > stats[1]["evals"]
 
 
 def test_serial_worker_device_mode_onehot(pkg):

@@ -118,6 +118,19 @@ def test_no_gpu_means_loud_failure():
     out = np.zeros(4, dtype=np.uint64)
     assert _lib.load().oth_legal_moves_batch(out.ctypes.data, out.ctypes.data, out.ctypes.data, 4, None) == -1
     assert "no gfx950" in _lib.last_error()
+    # the round-5 entry points too: a network handle can be made on the host, but nothing that would touch its device
+    # arrays -- the activation scale, the engine snapshot, the cache statistics -- runs without a device
+    import ctypes as C
+    L = _lib.load()
+    h = L.oth_net_create(2, 16, 8)
+    assert h
+    s = C.c_float(0)
+    assert L.oth_net_get_act_scale(h, C.byref(s)) == 0 and s.value == 16.0           # (a plain host field)
+    assert L.oth_net_set_act_scale(h, C.c_float(8.0)) != 0 and "no gfx950" in _lib.last_error()
+    L.oth_net_destroy(h)
+    stats = (C.c_int64 * 4)()
+    for rc in (L.oth_engine_snapshot(None, None), L.oth_engine_restore(None, None), L.oth_engine_cache_stats(None, stats, None)):
+        assert rc != 0
 
 
 def test_header_is_plain_c_and_links(tmp_path):
