@@ -1,5 +1,5 @@
 """Sweep of slot counts / lanes for one of bench.py's secondary legs (run_leg) in ONE GPU session, to size the leg:
-usage: python tools/leg_sweep.py configs3|configs4|cache  "games:lanes[:stagger[:step_games[:steps]]]" ...
+usage: python tools/leg_sweep.py headline|configs3|configs4|cache  "games:lanes[:stagger[:step_games[:steps]]]" ...
 prints one line per variant (games/s, roofline frac, positions per launch, trunk share of the step, tree ms, leg seconds)."""
 import importlib.util
 import json
@@ -17,6 +17,7 @@ bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
 BASE = {
+    "headline": dict(name="configs[1]", board=8, blocks=10, filters=128, sims=50, warmup=4, steps=8, step_games=1536),
     "configs3": dict(name="configs[3]", board=8, blocks=10, filters=128, sims=400, c_puct=1.5, temp_threshold=20, warmup=2, steps=4,
                      step_games=256),
     "configs4": dict(name="configs[4]", board=6, blocks=5, filters=64, sims=25, warmup=3, steps=4, step_games=32769),
