@@ -119,14 +119,11 @@ __device__ __forceinline__ unsigned long long h3_realclk() {   // 100 MHz consta
 #define OTH_HSTAMP(i)
 #endif
 
-// SHARE: the WPB waves of a workgroup run the SAME weight stream on different positions.  Unshared, every wave pulls all
-// NB*2 KB of a (k-step, tap) step from L2 itself (at 64 filters that is 8 KB per 60-84 MFMAs per wave: ~16 TB/s of L2 -> CU
-// traffic at full matrix rate -- the stream, not the matrix pipe, set this kernel's pace).  Shared, wave w loads fragments
-// [w*NB*2/WPB, (w+1)*NB*2/WPB) of step g+2 during step g, stores them to a three-stage LDS ring at the end of the step,
-// one s_barrier per step, and every wave reads the whole step g+1 from the ring while it computes step g: the L2 -> CU
-// stream is divided by WPB.  The waves march in lock step from then on, so a wave without positions (the last
-// workgroup of a ragged batch) computes on zero planes instead of leaving, and only whole workgroups exit early.
-template <int F, int BS, int P, int WPB, bool SHARE>
+// The WPB waves of a workgroup are independent (each streams its own weights from L2).  A build in which they shared the
+// stream through a three-stage LDS ring (one barrier per step, OTH_H3_SHARE) was measured 5-7 % slower in round 3 -- the
+// barrier and the ring's LDS round trip cost more than the quartered L2 -> CU stream saved -- and removed from the sources
+// in round 5 (DESIGN_HISTORY.md K3c; history at 274f240).
+template <int F, int BS, int P, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t* __restrict__ sb,
                                                        const uint64_t* __restrict__ ob,
                                                        const uint64_t* __restrict__ lgl, int64_t n,
@@ -147,14 +144,10 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 #endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pos0 = ((int64_t)blockIdx.x * WPB + wave) * P;
-    if (SHARE ? (int64_t)blockIdx.x * WPB * P >= nv : pos0 >= nv) return;   // unshared waves are independent
+    if (pos0 >= nv) return;   // the waves are independent
     const int n16 = lane & 15, g4 = lane >> 4;
     char* act = lds_h3 + (size_t)wave * G::WAVE_BYTES;
     float* scratch = (float*)(act + G::ACT_BYTES);
-    constexpr int FPW = SHARE ? NB * 2 / WPB : 0;          // fragments of a step this wave fetches from L2
-    constexpr int STEP_U4 = NB * 2 * 64;                   // uint4 per step: NB row blocks x (hi, lo) x 64 lanes
-    static_assert(!SHARE || (NB * 2) % WPB == 0, "fragments must divide among the waves");
-    uint4* ring = (uint4*)(lds_h3 + (size_t)WPB * G::WAVE_BYTES);   // SHARE: [3 stages][NB*2 fragments][64 lanes]
 
     // ---- zero both arrays (pad rows and guard cells stay zero for the whole network), then the input planes:
     //      channels 0..2 of chunk 0 = own / opponent / legal (bitboard.pyx:309-323) as exact f16 values 16.0 / 0
@@ -203,26 +196,7 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 
     uint32_t sat_bits = 0;   // largest activation seen (bit pattern); reaching the clamp raises the saturation flag
 #define OTH_SB __builtin_amdgcn_sched_barrier(0)
-    // SHARE: the layers' fragment streams are contiguous (h3_pack_weights appends them), so a global step index g runs
-    // over the whole network: step g lives at a.w + g * STEP_U4 and in ring stage g % 3.
-    const int total_steps = 9 + (a.n_layers - 1) * 9 * (F / 32);
-    int gstep = 0;
-    uint4 wq[NB * 2];          // unshared: the next step's fragments; shared: the next step's fragments read from the ring
-    uint4 gl0, gl1;            // shared: this wave's two fragments of step g+2 on their way from L2 to the ring (named
-                               // scalars: an array indexed by the unrolled row-block counter ends up in scratch memory)
-    static_assert(!SHARE || FPW == 2, "the shared build moves two fragments per wave and step");
-    if constexpr (SHARE) {     // prologue: steps 0 and 1 into stages 0 and 1, step 0 into registers, step 2 on its way
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int f = 0; f < FPW; ++f)
-                ring[(st * NB * 2 + wave * FPW + f) * 64 + lane] = a.w[((size_t)st * NB * 2 + wave * FPW + f) * 64 + lane];
-        gl0 = a.w[((size_t)2 * NB * 2 + wave * FPW) * 64 + lane];
-        gl1 = a.w[((size_t)2 * NB * 2 + wave * FPW + 1) * 64 + lane];
-        __syncthreads();
-#pragma unroll
-        for (int f = 0; f < NB * 2; ++f) wq[f] = ring[f * 64 + lane];
-    }
+    uint4 wq[NB * 2];          // the next step's fragments
     OTH_HSTAMP(0)
     for (int layer = 0; layer < a.n_layers; ++layer) {
         const int KK = layer == 0 ? 1 : F / 32;   // k-steps of 32 input channels (stem: planes 0..2 of chunk 0)
@@ -235,10 +209,8 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
 #pragma unroll
         for (int b = 0; b < NB; ++b) bias_q[b] = *(const float4*)(a.bias + (size_t)layer * F + b * 16 + 4 * g4);
         const float inv = a.inv[layer];
-        if constexpr (!SHARE) {
 #pragma unroll
-            for (int f = 0; f < NB * 2; ++f) wq[f] = wl[(size_t)f * 64];
-        }
+        for (int f = 0; f < NB * 2; ++f) wq[f] = wl[(size_t)f * 64];
         for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -250,14 +222,6 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                 }
                 int ns = kk * 9 + tap + 1;   // the next step's fragments (the last step re-reads its own: harmless)
                 ns = ns < nsteps ? ns : nsteps - 1;
-                // shared, during step g: (1) this wave's fragments of step g+2 -- requested from L2 during step g-1 -- go
-                // to ring stage (g+2) % 3 (free since the barrier of step g-2); (2) its fragments of step g+3 are
-                // requested (two steps of latency cover, clamped at the end: harmless re-read); (3) the whole step g+1
-                // is read from stage (g+1) % 3 (published before the barrier of step g-1); one barrier ends the step.
-                const int g3 = gstep + 3 < total_steps ? gstep + 3 : total_steps - 1;
-                const uint4* gsrc = a.w + ((size_t)g3 * NB * 2 + wave * FPW) * 64 + lane;
-                const uint4* rnext = ring + (size_t)((gstep + 1) % 3) * STEP_U4 + lane;
-                uint4* rdst = ring + (size_t)((gstep + 2) % 3) * STEP_U4 + (size_t)wave * FPW * 64 + lane;
                 const int dy = tap / 3 - 1, dx = tap % 3 - 1;
                 const int soff = (dy * BS + dx) * 16, koff = kk * 4 * NC * 16;
                 // source address of tile t: lanes whose source column is off the board (first / last column of a row
@@ -284,38 +248,16 @@ __global__ __launch_bounds__(64 * WPB) void k_trunk_h3(H3Args a, const uint64_t*
                         acc[b][t] = mfma_h<(F >= 64)>(wh[b], xl[cur], acc[b][t]);
                         OTH_SB;
                         if (b == 0 && t + 1 < T) xh[nxt] = *(const half8*)nsrc;
-                        if constexpr (!SHARE) {
-                            if (t == 0) wq[2 * b] = wl[((size_t)ns * NB * 2 + 2 * b) * 64];
-                        } else {
-                            if (t == 0 && b == 0) {
-                                rdst[0] = gl0;                                               // registers -> ring, step g+2
-                                gl0 = gsrc[0];                                               // L2 -> registers, step g+3
-                            }
-                            if (t == 0 && b == 1) {
-                                rdst[64] = gl1;
-                                gl1 = gsrc[64];
-                            }
-                            if (t == 1 % T) wq[2 * b] = rnext[(size_t)(2 * b) * 64];        // ring -> registers, step g+1
-                        }
+                        if (t == 0) wq[2 * b] = wl[((size_t)ns * NB * 2 + 2 * b) * 64];
                         OTH_SB;
                         acc[b][t] = mfma_h<(F >= 64)>(wh[b], xh[cur], acc[b][t]);
                         OTH_SB;
                         if (b == 0 && t + 1 < T) xl[nxt] = *(const half8*)(nsrc + HI);
-                        if constexpr (!SHARE) {
-                            if (t == 0) wq[2 * b + 1] = wl[((size_t)ns * NB * 2 + 2 * b + 1) * 64];
-                        } else {
-                            if (t == 1 % T) wq[2 * b + 1] = rnext[(size_t)(2 * b + 1) * 64];
-                        }
+                        if (t == 0) wq[2 * b + 1] = wl[((size_t)ns * NB * 2 + 2 * b + 1) * 64];
                         OTH_SB;
                         acc[b][t] = mfma_h<(F >= 64)>(wlo[b], xh[cur], acc[b][t]);
                         OTH_SB;
                     }
-                }
-                if constexpr (SHARE) {   // one barrier per step: stage (g+2) % 3 is complete, stage (g+1) % 3 is read
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    ++gstep;
                 }
             }
         }
@@ -510,16 +452,16 @@ int h3_pack_weights(oth_net* net) {
     return OTH_OK;
 }
 
-template <int F, int BS, int P, int WPB, bool SHARE>
+template <int F, int BS, int P, int WPB>
 static int launch_h3(oth_net* net, const H3Args& a, const uint64_t* sb, const uint64_t* ob, const uint64_t* lg,
                      int64_t n, const int32_t* n_valid, float* logp, float* v, hipStream_t stream) {
     using G = H3Geom<F, BS, P>;
-    constexpr size_t lds = (size_t)WPB * G::WAVE_BYTES + (SHARE ? 3 * (size_t)G::NB * 2 * 1024 : 0);   // + the weight ring
+    constexpr size_t lds = (size_t)WPB * G::WAVE_BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set_dev[64] = {};  // per device: the attribute belongs to the (function, device) pair
     bool& attr_set = attr_set_dev[net->device & 63];
     if (!attr_set) {
-        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_h3<F, BS, P, WPB, SHARE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk_h3<F, BS, P, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         attr_set = true;
     }
@@ -529,7 +471,7 @@ static int launch_h3(oth_net* net, const H3Args& a, const uint64_t* sb, const ui
     H3Args ad = a;
     OTH_HIP(hipMalloc(&ad.dbg, (size_t)grid * WPB * 8 * sizeof(unsigned long long)));
     OTH_HIP(hipMemset(ad.dbg, 0, (size_t)grid * WPB * 8 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB, SHARE>), dim3(grid), dim3(64 * WPB), lds, stream, ad, sb, ob, lg, n, n_valid,
+    hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB>), dim3(grid), dim3(64 * WPB), lds, stream, ad, sb, ob, lg, n, n_valid,
                        logp, v);
     OTH_HIP(hipStreamSynchronize(stream));
     {
@@ -548,7 +490,7 @@ static int launch_h3(oth_net* net, const H3Args& a, const uint64_t* sb, const ui
     }
     return OTH_OK;
 #endif
-    hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB, SHARE>), dim3(grid), dim3(64 * WPB), lds, stream, a, sb, ob, lg, n, n_valid,
+    hipLaunchKernelGGL((k_trunk_h3<F, BS, P, WPB>), dim3(grid), dim3(64 * WPB), lds, stream, a, sb, ob, lg, n, n_valid,
                        logp, v);
     OTH_HIP(hipGetLastError());
     return OTH_OK;
@@ -570,22 +512,13 @@ int h3_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uint6
     a.sat = net->d_sat;
     a.act_scale = net->act_scale;
     const int F = net->filters;
-#define OTH_H3_CASE(FF, BB, PP, WW, SH) \
-    if (F == FF && net->board == BB) return launch_h3<FF, BB, PP, WW, SH>(net, a, sb, ob, lg, n, n_valid, logp, v, stream)
-    // OTH_H3_SHARE=1: the four waves of a workgroup share the weight stream through an LDS ring (SHARE above).  Measured
-    // (round 3, same box, interleaved runs): 5x64 on 6x6 0.390 vs 0.371 ms, on 8x8 0.577 vs 0.535 ms per 4096 positions
-    // -- the barrier per step and the ring's LDS round trip cost more than the quartered L2 stream saves -- so the
-    // independent-waves build stays the default and the shared one stays selectable for further work.
-    static const bool share = getenv("OTH_H3_SHARE") != nullptr;
-    if (share) {
-        OTH_H3_CASE(64, 8, 1, 4, true);
-        OTH_H3_CASE(64, 6, 2, 4, true);
-    }
-    OTH_H3_CASE(64, 8, 1, 4, false);
-    OTH_H3_CASE(32, 8, 1, 4, false);
-    OTH_H3_CASE(64, 6, 2, 4, false);
-    OTH_H3_CASE(32, 6, 4, 4, false);
-    OTH_H3_CASE(128, 6, 1, 4, false);   // 128 filters on 6x6 (8x8 has k_trunk16); its ring would not fit beside four waves' planes
+#define OTH_H3_CASE(FF, BB, PP, WW) \
+    if (F == FF && net->board == BB) return launch_h3<FF, BB, PP, WW>(net, a, sb, ob, lg, n, n_valid, logp, v, stream)
+    OTH_H3_CASE(64, 8, 1, 4);
+    OTH_H3_CASE(32, 8, 1, 4);
+    OTH_H3_CASE(64, 6, 2, 4);
+    OTH_H3_CASE(32, 6, 4, 4);
+    OTH_H3_CASE(128, 6, 1, 4);   // 128 filters on 6x6 (8x8 has k_trunk16)
 #undef OTH_H3_CASE
     set_error("fp16-split wave trunk: unsupported filters %d / board %d", F, net->board);
     return OTH_E_UNSUPPORTED;

@@ -2,15 +2,14 @@
 //
 // Reference: /root/reference/src/model/net.py:182-205 (eval mode; BatchNorm folded at load time).
 //
-// Two builds of the same design live here (DESIGN.md "K3" has the measurements that chose between them):
-//   k_trunk16<X3, TP>  SHIPPED: v_mfma_f32_16x16x32_f16, TP = 2 positions per workgroup, two workgroups per CU,
-//                      tiles = board row of a position pair (padding rows skipped).  Further down in this file.
-//                      TP = 1 (tile = two rows of one position) serves launches of <= 256 positions: half the
-//                      latency when every workgroup has a CU to itself anyway.
-//   k_trunk<X3>        first version, kept for A/B (OTH_MFMA_SHAPE=32): v_mfma_f32_32x32x16_f16, 4 positions per
-//                      workgroup, one workgroup per CU.
+//   k_trunk16<X3, TP>  v_mfma_f32_16x16x32_f16, TP = 2 positions per workgroup, two workgroups per CU, tiles = board row
+//                      of a position pair (padding rows skipped).  TP = 1 (tile = two rows of one position) serves
+//                      launches of <= 256 positions: half the latency when every workgroup has a CU to itself anyway;
+//                      TP = 4 is the single-pass f16 precision's build (its TP = 2 instantiation spills registers).
+//   (The first version of this kernel -- v_mfma_f32_32x32x16_f16, four positions per workgroup, OTH_MFMA_SHAPE=32 -- was
+//   removed in round 5: slower since round 1, DESIGN_HISTORY.md section 7.1; it is in the history at 274f240.)
 //
-// Common design (MI355X-first):
+// Design (MI355X-first):
 //   * a workgroup of 4 waves carries its positions through the stem, all residual blocks and both heads in one
 //     launch; the activations NEVER leave the CU: LDS [cell][hi 128 x f16 | lo 128 x f16] (512 B per cell), every
 //     3x3 tap reads them in place (implicit GEMM, no im2col copy); out-of-board taps read a zeroed cell.
@@ -41,13 +40,11 @@
 namespace oth {
 
 using half8 = _Float16 __attribute__((ext_vector_type(8)));
-using f32x16 = float __attribute__((ext_vector_type(16)));
 using half4 = _Float16 __attribute__((ext_vector_type(4)));
 
-constexpr int kTilePos = 4;                    // positions per workgroup
 constexpr int kCellBytes = 512;                // 256 B hi + 256 B lo
 constexpr int kActBytes = 256 * kCellBytes;    // 131072
-constexpr int kZeroOff = kActBytes;            // zero cell (512 B)
+
 constexpr int kScratchOff = kActBytes + 512;   // stem im2col (16 KiB) / head scratch
 constexpr int kLdsBytes = kScratchOff + 16384;
 constexpr float kActClamp = 60000.0f;          // activations x act_scale are clamped to the f16 range of the hi parts: activations
@@ -55,7 +52,6 @@ constexpr float kActClamp = 60000.0f;          // activations x act_scale are cl
 
 struct MfmaWeights {
     int blocks = 0;
-    int shape = 32;            // MFMA shape the fragments are packed for: 32 (32x32x16) or 16 (16x16x32)
     uint4* d_w = nullptr;      // fragments: [layer][step 0..71][wave 0..3][plane hi,lo][64 lanes] x 16 B
     uint4* d_stem = nullptr;   // [step 0..1][wave][plane][64 lanes]
     float* d_bias = nullptr;   // [1 + 2*blocks][128], x act_scale (register_scaled_bias)
@@ -104,252 +100,8 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// LDS address of this lane's activation fragment: cell base (or the zero cell) | swizzled 16-B chunk
-#define OTH_AFRAG(AA, HK, q) (lds + ((AA)[(q) & 7] | ((((uint32_t)(((q) >> 3) << 1)) ^ (HK)) << 4)))
-
-template <bool X3>
-__global__ __launch_bounds__(256, 1) void k_trunk(MfmaArgs a, const uint64_t* __restrict__ sb,
-                                                  const uint64_t* __restrict__ ob,
-                                                  const uint64_t* __restrict__ lgl, int64_t n,
-                                                  const int32_t* __restrict__ n_valid, float* __restrict__ logp,
-                                                  float* __restrict__ vout) {
-    constexpr int PD = X3 ? 2 : 4;  // activation fragments in flight ahead of the MFMAs (tiles)
-    constexpr int PB = X3 ? 2 : 4;  // weight fragments in flight (k-steps)
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    int64_t nv = n;
-    if (n_valid) {
-        const int64_t k = *n_valid;
-        nv = k < n ? k : n;
-    }
-    const int64_t pos0 = (int64_t)blockIdx.x * kTilePos;
-    if (pos0 >= nv) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, r = lane & 31;
-
-    // ---------------- stem input: im2col of the three bit planes, [256 cells][32 k] f16, k = tap*3 + plane
-    {
-        const int p = tid >> 6, c = tid & 63, y = c >> 3, x = c & 7;
-        const bool live = pos0 + p < nv;
-        const uint64_t b0 = live ? sb[pos0 + p] : 0, b1 = live ? ob[pos0 + p] : 0, b2 = live ? lgl[pos0 + p] : 0;
-        _Float16 vals[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) vals[i] = (_Float16)0.0f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const int s = ok ? yy * 8 + xx : 0;
-            vals[tap * 3 + 0] = (ok && ((b0 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
-            vals[tap * 3 + 1] = (ok && ((b1 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
-            vals[tap * 3 + 2] = (ok && ((b2 >> s) & 1ULL)) ? (_Float16)a.act_scale : (_Float16)0.0f;
-        }
-        half8* dst = (half8*)(lds + kScratchOff + tid * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            half8 t;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = vals[q * 8 + j];
-            dst[q] = t;
-        }
-        if (tid < 32) ((uint4*)(lds + kZeroOff))[tid] = make_uint4(0, 0, 0, 0);  // the zero cell
-    }
-    __syncthreads();
-
-    // MFMA roles: A operand = weights (rows = 32 output channels of this wave), B operand =
-    // activations (columns = the 32 cells of a tile).  D[m][n]: lane holds column n = r (its cell) and
-    // rows m = (i&3) + 8*(i>>2) + 4*h, i.e. four groups of 4 CONSECUTIVE channels -> 8-byte LDS stores.
-    f32x16 acc[8], res[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    // ---------------- stem conv as a K=32 GEMM (net.py:195)
-    {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint4* wp = a.stem + ((size_t)(kk * 4 + wave) * 2) * 64 + lane;
-            const uint4 wh4 = wp[0], wl4 = wp[64];
-            const half8 wh = __builtin_bit_cast(half8, wh4), wlo = __builtin_bit_cast(half8, wl4);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const half8 xh = *(const half8*)(lds + kScratchOff + (t * 32 + r) * 64 + (kk * 2 + h) * 16);
-                if (X3) acc[t] = mfma16(wlo, xh, acc[t]);
-                acc[t] = mfma16(wh, xh, acc[t]);
-            }
-        }
-    }
-
-    // write-side constants: this lane's cell within a tile is r; its swizzle key; per channel group g
-    // the byte offset of the 8-byte half-chunk holding channels wave*32 + 8g + 4h .. +3
-    const uint32_t keyw = (uint32_t)((r & 7) | (((r >> 3) & 1) << 3));
-    uint32_t wr_off[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        wr_off[g] = (uint32_t)r * kCellBytes + ((((uint32_t)(wave * 4 + g)) ^ keyw) << 4) + 8u * (uint32_t)h;
-    const int ch0 = wave * 32 + 4 * h;  // + 8g + e
-
-    // Activations and the residual are carried PRE-SCALED by a.act_scale (ReLU commutes with a positive
-    // scale): res16 = act_scale * x (16 by default).  bias16/inv16 are prepared on the host.
-    const int n_layers = 1 + a.n_res_layers;
-    uint32_t sat_bits = 0;
-    uint4 wq_h[PB], wq_l[PB];  // weight-fragment ring of the conv that FOLLOWS the current epilogue
-    for (int layer = 0; layer < n_layers; ++layer) {
-        const bool last = layer == n_layers - 1;
-        // request the first weight fragments of conv `layer+1` now: their L2 latency hides under the epilogue
-        const uint4* wl = a.w + ((size_t)layer * 72 * 4 + wave) * 128 + lane;  // + step*512 (+64: lo)
-        if (!last) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                wq_h[i] = wl[(size_t)i * 512];
-                if (X3) wq_l[i] = wl[(size_t)i * 512 + 64];
-            }
-        }
-        // ---------------- epilogue of conv `layer` (0 = stem): scale back, bias, skip, ReLU, re-split
-        float4 b4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = *(const float4*)(a.bias + layer * 128 + ch0 + 8 * g);
-        const float inv = a.inv[layer];
-        const bool add_res = layer > 0 && (layer & 1) == 0;   // second conv of a block (net.py:58)
-        const bool set_res = layer == 0 || add_res;
-        lds_barrier();  // every wave has finished reading the previous activations
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float vs[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * g + e;
-                    const float bb = e == 0 ? b4[g].x : (e == 1 ? b4[g].y : (e == 2 ? b4[g].z : b4[g].w));
-                    float v = fmaf(acc[t][i], inv, bb);
-                    if (add_res) v += res[t][i];
-                    v = __builtin_amdgcn_fmed3f(v, 0.f, kActClamp);  // ReLU + f16 range clamp (x <= 3750)
-                    sat_bits = max(sat_bits, __float_as_uint(v));
-                    if (set_res) res[t][i] = v;
-                    acc[t][i] = 0.f;
-                    vs[e] = v;
-                }
-                if (!last) {
-                    half4 hi;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)vs[e];
-                    char* dst = lds + (uint32_t)(t * 32) * kCellBytes + wr_off[g];
-                    *(half4*)dst = hi;
-                    if (X3) {
-                        half4 lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(vs[e] - (float)hi[e]);
-                        *(half4*)(dst + 256) = lo;
-                    }
-                }
-            }
-        }
-        if (last) break;
-        lds_barrier();
-
-        // ---------------- conv `layer+1`: 9 taps x 8 k-steps of 16 input channels, one software pipeline
-        // over all 576 (tap, k-step, tile) fragments: fragment q+PD is requested before the MFMAs of q,
-        // across tap boundaries too.
-        uint32_t A[8], An[8];
-        uint32_t hk, hkn;
-        // lane-constant tap geometry
-        auto tap_setup = [&](int tap, uint32_t(&Ao)[8], uint32_t& hko) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int yo = (r >> 3) + dy, xs = (r & 7) + dx;   // yo relative to the tile's first row
-            const bool xok = xs >= 0 && xs < 8;
-            hko = (uint32_t)(h ^ ((xs & 7) | ((yo & 1) << 3)));
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int ys = (t & 1) * 4 + yo;
-                const bool ok = xok && ys >= 0 && ys < 8;
-                Ao[t] = ok ? (uint32_t)((t >> 1) * 64 + ys * 8 + xs) * kCellBytes : (uint32_t)kZeroOff;
-            }
-        };
-        tap_setup(0, A, hk);
-        half8 xh[PD + 1], xl[PD + 1];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            xh[q] = *(const half8*)OTH_AFRAG(A, hk, q);
-            if (X3) xl[q] = *(const half8*)(OTH_AFRAG(A, hk, q) + 256);
-        }
-        for (int tap = 0; tap < 9; ++tap) {
-            tap_setup(tap < 8 ? tap + 1 : 8, An, hkn);  // next tap's geometry (last tap: harmless re-reads)
-            half8 wh, wlo;
-#pragma unroll
-            for (int q = 0; q < 64; ++q) {
-                {   // prefetch fragment q+PD (slot rotation: 64 % (PD+1) tiles per tap)
-                    const int qq = q + PD;
-                    const int slot = (q + PD) % (PD + 1);
-                    if (qq < 64) {
-                        xh[slot] = *(const half8*)OTH_AFRAG(A, hk, qq);
-                        if (X3) xl[slot] = *(const half8*)(OTH_AFRAG(A, hk, qq) + 256);
-                    } else {
-                        xh[slot] = *(const half8*)OTH_AFRAG(An, hkn, qq - 64);
-                        if (X3) xl[slot] = *(const half8*)(OTH_AFRAG(An, hkn, qq - 64) + 256);
-                    }
-                }
-                if ((q & 7) == 0) {  // new k-step: take its weight fragments, refill the ring slot
-                    const int kk = q >> 3, slot = kk % PB;
-                    wh = __builtin_bit_cast(half8, wq_h[slot]);
-                    if (X3) wlo = __builtin_bit_cast(half8, wq_l[slot]);
-                    int nstep = tap * 8 + kk + PB;
-                    nstep = nstep < 72 ? nstep : 71;  // tail: re-read the last fragment (harmless)
-                    wq_h[slot] = wl[(size_t)nstep * 512];
-                    if (X3) wq_l[slot] = wl[(size_t)nstep * 512 + 64];
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above ahead of the MFMAs below
-                const int t = q & 7;
-                if (X3) {
-                    acc[t] = mfma16(wh, xl[q % (PD + 1)], acc[t]);
-                    acc[t] = mfma16(wlo, xh[q % (PD + 1)], acc[t]);
-                }
-                acc[t] = mfma16(wh, xh[q % (PD + 1)], acc[t]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // rotate: the ring slots continue seamlessly only if 64 % (PD+1) == 0; otherwise re-base them
-            if constexpr (64 % (PD + 1) != 0) {
-                half8 th[PD + 1], tl[PD + 1];
-#pragma unroll
-                for (int i = 0; i < PD + 1; ++i) { th[i] = xh[i]; if (X3) tl[i] = xl[i]; }
-#pragma unroll
-                for (int i = 0; i < PD; ++i) {
-                    xh[i] = th[(64 + i) % (PD + 1)];
-                    if (X3) xl[i] = tl[(64 + i) % (PD + 1)];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) A[t] = An[t];
-            hk = hkn;
-        }
-    }
-
-    // ---------------- heads (fp32 VALU): final activations (in `res`) -> LDS [256 cells][128] f32
-    if (sat_bits >= __float_as_uint(kActClamp)) atomicOr(a.sat, 1);
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float us = 1.0f / a.act_scale;
-            const float4 o = make_float4(res[t][4 * g] * us, res[t][4 * g + 1] * us, res[t][4 * g + 2] * us,
-                                         res[t][4 * g + 3] * us);
-            *(float4*)(lds + (size_t)(t * 32 + r) * 512 + (size_t)(ch0 + 8 * g) * 4) = o;
-        }
-    __syncthreads();
-    for (int p = 0; p < kTilePos; ++p) {
-        if (pos0 + p >= nv) break;  // uniform across the block
-        heads_forward(a.heads, 128, (const float*)(lds + (size_t)p * 64 * 512), 128, (float*)(lds + kScratchOff),
-                      logp + (pos0 + p) * 65, vout + pos0 + p);
-    }
-}
-
 // =================================================================================================
-// Shipped variant: v_mfma_f32_16x16x32_f16, TP positions per workgroup (same fp16x3 arithmetic).
+// k_trunk16: v_mfma_f32_16x16x32_f16, TP positions per workgroup.
 // Per wave: 2 row blocks of 16 output channels x NT tiles of 16 cells; one k-step = 32 input channels.
 //   A operand (weights):     lane l holds W[row = l&15][k = 8*(l>>4) + j]
 //   B operand (activations): lane l holds X[k = 8*(l>>4) + j][col = l&15 = cell of the tile]
@@ -773,34 +525,6 @@ static inline void split_f16(float v, uint16_t& hi, uint16_t& lo) {
     memcpy(&lo, &ll, 2);
 }
 
-// B fragment of v_mfma_f32_32x32x16_f16: lane l holds B[k = 8*(l>>5) + j][col = l&31], j = 0..7
-static float pack_conv(const FoldedConv& c, int k_total, std::vector<uint16_t>& out, size_t base, int steps,
-                       const std::vector<int>& k_map /* gemm k -> index into [tap*cin + ci], -1 = zero */) {
-    float mx = 0.f;
-    for (float x : c.w) mx = fmaxf(mx, fabsf(x));
-    int e = 0;
-    if (mx > 0.f) e = (int)floorf(log2f(16384.0f / mx));  // largest |w| lands in [8192, 16384]
-    if (e > 24) e = 24;
-    if (e < -24) e = -24;
-    const float scale = ldexpf(1.0f, e);
-    (void)k_total;
-    for (int s = 0; s < steps; ++s)
-        for (int w = 0; w < 4; ++w)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int k = s * 16 + 8 * (l >> 5) + j, col = w * 32 + (l & 31);
-                    const int src = k_map[k];
-                    const float v = src < 0 ? 0.f : c.w[(size_t)src * c.cout + col] * scale;
-                    uint16_t hi, lo;
-                    split_f16(v, hi, lo);
-                    const size_t frag = base + ((size_t)(s * 4 + w) * 2) * 64 * 8;  // in halfs
-                    out[frag + (size_t)l * 8 + j] = hi;
-                    out[frag + 64 * 8 + (size_t)l * 8 + j] = lo;
-                }
-    return scale;
-}
-
-
 // A fragment of v_mfma_f32_16x16x32_f16: lane l holds W[row = l&15][k = 8*(l>>4) + j].  Stream per layer:
 // [step (32 channels)][wave][rb0 hi, rb0 lo, rb1 hi, rb1 lo][64 lanes] x 16 B.
 static float pack_conv16(const FoldedConv& c, std::vector<uint16_t>& out, size_t base, int steps,
@@ -851,20 +575,17 @@ int mfma_pack_weights(oth_net* net, int precision) {
     const size_t layer_halfs = (size_t)72 * 4 * frag_halfs;
     std::vector<uint16_t> w((size_t)L * layer_halfs), stem((size_t)2 * 4 * frag_halfs);
     std::vector<float> bias((size_t)(L + 1) * 128), inv(L + 1);
-    const char* shp = getenv("OTH_MFMA_SHAPE");
-    mw->shape = (shp && atoi(shp) == 32) ? 32 : 16;  // 16x16x32 is the default (measured faster: DESIGN.md)
     std::vector<int> km(1152);
     for (int k = 0; k < 1152; ++k) km[k] = k;  // k = tap*128 + ci, steps ordered (tap, kk)
     std::vector<int> ks(32, -1);               // stem: gemm k = tap*3 + plane for k < 27
     for (int k = 0; k < 27; ++k) ks[k] = k;
     {
-        const float sc = mw->shape == 16 ? pack_conv16(hn.stem, stem, 0, 1, ks) : pack_conv(hn.stem, 32, stem, 0, 2, ks);
+        const float sc = pack_conv16(hn.stem, stem, 0, 1, ks);
         inv[0] = 1.0f / sc;  // accumulator holds (16 x) * (sc w): divide by sc to get 16 * y
         for (int i = 0; i < 128; ++i) bias[i] = hn.stem.bias[i];
     }
     for (int l = 0; l < L; ++l) {
-        const float sc = mw->shape == 16 ? pack_conv16(hn.res[l], w, (size_t)l * layer_halfs, 36, km)
-                                         : pack_conv(hn.res[l], 1152, w, (size_t)l * layer_halfs, 72, km);
+        const float sc = pack_conv16(hn.res[l], w, (size_t)l * layer_halfs, 36, km);
         inv[l + 1] = 1.0f / sc;
         for (int i = 0; i < 128; ++i) bias[(size_t)(l + 1) * 128 + i] = hn.res[l].bias[i];
     }
@@ -905,37 +626,23 @@ int mfma_forward(oth_net* net, const uint64_t* sb, const uint64_t* ob, const uin
     constexpr int kLds2 = 2 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 2: 74 240 B, two workgroups per CU
     constexpr int kLds1 = 1 * 64 * kCellBytes + 512 + 2 * 4096;  // TP = 1 (heads scratch needs the 8 KiB)
     if (!attr_set) {
-        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1));
         OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
-        OTH_HIP(hipFuncSetAttribute((const void*)k_trunk16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
         attr_set = true;
     }
     const bool x3 = net->precision == OTH_PREC_F16X3 || net->precision == OTH_PREC_F16X3_DIRECT;
+    // fp16x3: two 2-position workgroups per CU; launches that cannot fill the chip (n <= 256: every workgroup has a CU to
+    // itself either way) run one position per workgroup -- twice the CUs, half the MFMAs per workgroup: 0.34 -> ~0.2 ms per
+    // launch.  OTH_TRUNK_TP=1|2 (read per call) forces a build: the switch the variants test uses to compare the two on one
+    // batch.  The single-pass f16 precision runs four positions per workgroup (its TP = 2 instantiation spills registers).
     const char* tpe = getenv("OTH_TRUNK_TP");
-    // default: two 2-position workgroups per CU for the fp16x3 build; the single-pass build runs 4 positions per
-    // workgroup (its TP = 2 instantiation spills registers)
-    // launches that cannot fill the chip (n <= 256: every workgroup has a CU to itself either way) run one
-    // position per workgroup -- twice the CUs, half the MFMAs per workgroup: 0.34 -> ~0.2 ms per launch
-    const int tp_auto = x3 ? (n <= 256 ? 1 : 2) : 4;
     const int tp_env = tpe ? atoi(tpe) : 0;
-    const int tp = net->mfma->shape != 16 ? 4 : ((tp_env == 4 || tp_env == 2 || (tp_env == 1 && x3)) ? tp_env : tp_auto);
+    const int tp = !x3 ? 4 : ((tp_env == 1 || tp_env == 2) ? tp_env : (n <= 256 ? 1 : 2));
     const unsigned grid = (unsigned)((n + tp - 1) / tp);
-    if (net->mfma->shape == 16 && tp == 1) {
-        hipLaunchKernelGGL((k_trunk16<true, 1>), dim3(grid), dim3(256), kLds1, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    } else if (net->mfma->shape == 16 && tp == 2) {
-        if (x3) hipLaunchKernelGGL((k_trunk16<true, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
-        else hipLaunchKernelGGL((k_trunk16<false, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    } else if (net->mfma->shape == 16) {
-        if (x3) hipLaunchKernelGGL((k_trunk16<true, 4>), dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
-        else hipLaunchKernelGGL((k_trunk16<false, 4>), dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    } else {
-        if (x3) hipLaunchKernelGGL(k_trunk<true>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
-        else hipLaunchKernelGGL(k_trunk<false>, dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
-    }
+    if (tp == 1) hipLaunchKernelGGL((k_trunk16<true, 1>), dim3(grid), dim3(256), kLds1, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    else if (tp == 2) hipLaunchKernelGGL((k_trunk16<true, 2>), dim3(grid), dim3(256), kLds2, stream, a, sb, ob, lg, n, n_valid, logp, v);
+    else hipLaunchKernelGGL((k_trunk16<false, 4>), dim3(grid), dim3(256), kLdsBytes, stream, a, sb, ob, lg, n, n_valid, logp, v);
     OTH_HIP(hipGetLastError());
 #ifdef OTH_STAMPS
     {
