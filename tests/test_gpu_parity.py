@@ -766,6 +766,60 @@ def test_rescue_replays_the_call_from_its_start_state(pkg):
                                           for p, q in zip(d1, d2))
 
 
+def test_bench_workload_rescues_across_lanes(pkg):
+    """bench.py's own step (Workload.play): two lanes on two streams and host threads share ONE evaluator, every lane
+    snapshots its stream before the step, and the rescue of a saturated launch is decided where both lanes have joined --
+    both are then restored and the step is replayed.  With a network that saturates at the default activation scale the
+    steps must return, lane by lane, the tuples of a workload whose evaluator had the settled scale from the start."""
+    import importlib.util
+    import os
+    import types
+    import warnings
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    x = (torch.rand(64, 3, 8, 8, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    plain = _trained_like(pkg, 2, 64, 8)
+    amax1, _ = _max_activation(plain.cuda(), x)
+    net = _trained_like(pkg, 2, 64, 8, boost=6000.0 / amax1)
+    proxy = types.SimpleNamespace(**{k: getattr(pkg, k) for k in dir(pkg) if not k.startswith("__")})
+    proxy.OthelloResNet = lambda *a_, **k_: net           # Workload builds its network by seed: hand it the boosted one
+
+    def set_scale(ev, s_):
+        pkg._lib.call("oth_net_set_act_scale", ev.handle, C.c_float(s_))
+
+    def tuples(parts):
+        return [tuple(t_.clone() for t_ in lane) for lane in parts]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = bench.Workload(proxy, torch, 8, 2, 64, 6, 32, 2, 5, 16)      # 32 slots in two lanes, 6 sims, steps of 16 games
+        g1, p1 = w.play(16)
+        t1 = tuples(p1)
+        s1 = w.ev.act_scale
+        assert s1 < 16.0 and len(w.ev.rescues) >= 1 and g1 >= 16
+        set_scale(w.ev, 16.0)                                                # the second step saturates again, in mid-stream
+        k = len(w.ev.rescues)
+        g2, p2 = w.play(16)
+        t2 = tuples(p2)
+        s2 = w.ev.act_scale
+        assert len(w.ev.rescues) > k and s2 < 16.0
+        ref = bench.Workload(proxy, torch, 8, 2, 64, 6, 32, 2, 5, 16)
+        set_scale(ref.ev, s1)
+        h1, q1 = ref.play(16)
+        u1 = tuples(q1)
+        set_scale(ref.ev, s2)
+        h2, q2 = ref.play(16)
+        u2 = tuples(q2)
+        assert ref.ev.rescues == [] and (g1, g2) == (h1, h2)
+    for got, want in ((t1, u1), (t2, u2)):
+        assert len(got) == len(want) == 2
+        for lane_g, lane_w in zip(got, want):
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(lane_g, lane_w))
+    assert w.counters() == ref.counters()
+
+
 def test_trunk_on_trained_like_weights(pkg):
     """fp16x3 trunk with non-trivial BatchNorm statistics, uneven per-channel scales and peaked policies (what a
     trained checkpoint looks like, unlike the seeded-random init): within 1e-4 of torch fp32 and no noisier
