@@ -110,6 +110,38 @@ def all_gather_replay(states, pis, zs, group=None, force=False):
     return out[0], out[1], out[2], counts
 
 
+def broadcast_model(model, src=0, group=None):
+    """Rank `src`'s weights to every rank -- the once-per-iteration step of a replicated trainer (every rank
+    trains the same replicated model on the same all-gathered tuples, or only rank `src` trains and the others follow).  All
+    floating parameters and buffers travel as ONE flattened tensor (11.9 MB fp32 for 10x128: a single collective, not 144),
+    the int64 `num_batches_tracked` counters as a second one; tensors are written back in place, so the evaluator's
+    `refresh()` sees the new version counters.  A no-op outside an initialised process group or at world size 1.  The
+    reference is single-process (/root/reference/src/train/trainer.py:180-185 trains the model the worker reads)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    tensors = list(model.parameters()) + list(model.buffers())
+    moved = 0
+    for is_float in (True, False):
+        part = [t for t in tensors if t.is_floating_point() == is_float]
+        if not part:
+            continue
+        dev = part[0].device
+        if dist.get_backend(group) == "gloo":
+            dev = torch.device("cpu")
+        flat = torch.cat([t.detach().reshape(-1).to(device=dev, dtype=part[0].dtype) for t in part])
+        dist.broadcast(flat, src=src, group=group)
+        at = 0
+        with torch.no_grad():
+            for t in part:
+                n = t.numel()
+                t.copy_(flat[at: at + n].view_as(t))
+                at += n
+        moved += flat.numel() * flat.element_size()
+    return moved
+
+
 class DistributedSelfPlayWorker:
     """``execute_episodes`` with the reference's signature for a job of WORLD_SIZE processes: each rank
     plays ``shard_episodes`` games on its own GPU, then all ranks receive all tuples."""
