@@ -271,7 +271,9 @@ int oth_selfplay_device_ptrs(oth_engine *e, float **states, float **pis, float *
  * network launches saturated (oth_net_saturated) can be played again from exactly the state it started in after
  * oth_net_set_act_scale: restore puts that state back, forgets the games the abandoned call finished (their ring
  * entries are free again) and clears the evaluation cache.  Games are keyed by (seed, game id, ply), so the repeated call
- * replays the same games.  snapshot: call when no step / search is in progress; restore: needs a snapshot. */
+ * replays the same games.  (With the evaluation cache on, roots that were taken from the cache BEFORE the snapshot keep their
+ * rows: outputs of earlier launches that did not saturate -- valid, though computed at the previous activation scale.)
+ * snapshot: call when no step / search is in progress; restore: needs a snapshot. */
 int oth_engine_snapshot(oth_engine *e, void *stream);
 int oth_engine_restore(oth_engine *e, void *stream);
 
