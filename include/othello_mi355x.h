@@ -177,8 +177,9 @@ typedef struct {
     double dirichlet_epsilon;  /* mcts.py:34 */
     int32_t store_late_onehot; /* 1: SelfPlayWorker semantics (pi stored one-hot after the threshold, L14);
                                   0: ParallelSelfPlayWorker semantics (always the visit distribution, L15) */
-    int32_t eval_cache_log2;   /* 0 = off (default).  >0: transposition table of 2^n network results keyed by
-                                  position, reused bit-identically within a run (cleared at every run start);
+    int32_t eval_cache_log2;   /* 0 = off (default).  >0: transposition table of 2^n network results (2^(n-1) sets of two
+                                  ways, 280 B per entry) keyed by position, reused bit-identically within a run (cleared at
+                                  every run start / stream step);
                                   skips re-evaluating positions the search has already evaluated (no reference
                                   counterpart: the reference re-evaluates; outputs are identical) */
     int32_t board_size;        /* 0 or 8: the reference's 8x8 game.  6: the same engine on a 6x6 board (BASELINE

@@ -80,10 +80,11 @@ struct Dev {  // device pointers + scalars handed to every kernel by value
     int32_t* done_list;      // [hist_cap] ring of finished game ids in completion order
     unsigned long long* counters;  // [blocks][8]
     uint64_t seed;
-    // optional evaluation cache (transposition table of network outputs), direct-mapped
+    // optional evaluation cache (transposition table of network outputs): C entries = C/2 sets of TWO ways (round 5: a set's
+    // ways are entries 2s and 2s+1; an insert takes an empty way, else replaces the way inserted longer ago)
     uint64_t* ck;       // [C][2] keys (self, opp); all-ones = empty
     float* cv;          // [C][66] raw policy (65) + value
-    int32_t* clk;       // [C] claim epoch of the last insert
+    int32_t* clk;       // [C] claim epoch of the last insert (also the age of the entry: FIFO within a set)
     float* cres;        // [n_slots][66] result row copied at lookup time (an insert may replace the entry later)
     uint32_t cmask;     // C - 1, 0 = cache disabled
     int32_t cepoch;
@@ -174,14 +175,20 @@ __device__ __forceinline__ uint32_t cache_slot(const Dev& d, uint64_t sb, uint64
     h = (h ^ (h >> 31)) ^ sb;
     h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ULL;
     h = (h ^ (h >> 27)) * 0x94D049BB133111EBULL;
-    return (uint32_t)(h ^ (h >> 31)) & d.cmask;
+    return (uint32_t)(h ^ (h >> 31)) & d.cmask & ~1u;   // way 0 of the position's set (way 1 = + 1)
 }
 // On a hit the 66-float result row is copied into the game's own row cres[g] right away: the entry may be
 // replaced by an insert before the expansion (next launch) reads it.  Whole wave calls; returns hit or not.
 __device__ __forceinline__ bool cache_fetch(const Dev& d, int g, uint64_t sb, uint64_t ob, int lane) {
     if (d.cmask == 0) return false;
-    const uint32_t cs = cache_slot(d, sb, ob);
-    if (!(d.ck[2 * (size_t)cs] == sb && d.ck[2 * (size_t)cs + 1] == ob)) return false;
+    uint32_t cs = cache_slot(d, sb, ob);
+    const ulonglong2 k0 = *(const ulonglong2*)(d.ck + 2 * (size_t)cs), k1 = *(const ulonglong2*)(d.ck + 2 * (size_t)cs + 2);
+    if (k0.x == sb && k0.y == ob) {
+    } else if (k1.x == sb && k1.y == ob) {
+        cs += 1;
+    } else {
+        return false;
+    }
     const float* src = d.cv + (size_t)cs * 66;
     float* dst = d.cres + (size_t)g * 66;   // [0, NPOL) policy, [65] value (row layout shared by both board sizes)
     dst[lane] = src[lane];
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
     const int slot = d.eval_slot[g];
     if (slot < 0) return;
     const uint64_t sb = d.leaf_self[g], ob = d.leaf_opp[g];
-    const uint32_t cs = cache_slot(d, sb, ob);
+    uint32_t cs = cache_slot(d, sb, ob);
     int own = 0;
     if (lane == 0) {
         // statistics: first evaluation of this position since the clear, or a repeat?  (second hash: the slot hash's
@@ -286,13 +293,30 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
         const bool seen = atomicOr(&d.cseen[bit >> 6], m) & m;
         unsigned long long* st = d.cstat + (size_t)blockIdx.x * 4;
         atomicAdd(&st[seen ? 1 : 0], 1ULL);
-        own = atomicMax(&d.clk[cs], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
+        // the way to write: the position's own entry if it is there already (evaluated twice since the clear: refresh it), an
+        // empty way, else the way inserted longer ago; if another wave claimed that way in THIS launch, the other way; if
+        // that is taken too, the result is not cached (it was evaluated anyway)
+        const ulonglong2 ka = *(const ulonglong2*)(d.ck + 2 * (size_t)cs), kb = *(const ulonglong2*)(d.ck + 2 * (size_t)cs + 2);
+        const bool ea = ka.x == ~0ULL && ka.y == ~0ULL, eb = kb.x == ~0ULL && kb.y == ~0ULL;
+        int first;
+        if (ka.x == sb && ka.y == ob) first = 0;
+        else if (kb.x == sb && kb.y == ob) first = 1;
+        else if (ea || eb) first = ea ? 0 : 1;
+        else first = d.clk[cs] <= d.clk[cs + 1] ? 0 : 1;
+        int way = first;
+        own = atomicMax(&d.clk[cs + way], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
+        if (!own) {
+            way = first ^ 1;
+            own = atomicMax(&d.clk[cs + way], d.cepoch) < d.cepoch;
+        }
         if (own) {
-            const uint64_t k0 = d.ck[2 * (size_t)cs], k1 = d.ck[2 * (size_t)cs + 1];
-            if (!(k0 == ~0ULL && k1 == ~0ULL) && !(k0 == sb && k1 == ob)) atomicAdd(&st[2], 1ULL);   // a live entry of another position goes
+            const ulonglong2 kw = way == 0 ? ka : kb;
+            if (!(kw.x == ~0ULL && kw.y == ~0ULL) && !(kw.x == sb && kw.y == ob)) atomicAdd(&st[2], 1ULL);   // a live entry of another position goes
+            cs += (uint32_t)way;
         }
     }
     if (!__shfl(own, 0)) return;
+    cs = __shfl(cs, 0);
     float* dst = d.cv + (size_t)cs * 66;
     if (lane < CELLS) dst[lane] = policy[(size_t)slot * NP + lane];
     if (lane == 0) {
