@@ -46,6 +46,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them used by the default stream): with four lanes two
+# of them then share a queue and their launches serialise -- configs[4] on four lanes measured 25.7 k games/s with the default
+# and 27.9-28.1 k with 8 (profiles/r05_hw_queues.log; two- and three-lane workloads are unaffected).  Read when the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F16_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3         # fp32-input MFMA (v_mfma_f32_16x16x4_f32) peak, MI355X_MICROARCH.md
@@ -274,7 +278,13 @@ class Workload:
         self.engs = [pkg.SearchEngine(games // self.lanes, sims, temperature_threshold=temp_threshold, c_puct=c_puct,
                                       evaluator=self.ev, eval_cache_log2=eval_cache) for _ in range(self.lanes)]
         self.dev = torch.cuda.current_device()
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.lanes)] if self.lanes > 1 else [None]
+        # the lanes' streams are made ONCE per process and device (engine.lane_streams: with new streams per workload the two
+        # streams of every second two-lane workload shared a hardware queue and the workload lost 8-10 %;
+        # OTHELLO_BENCH_NEW_STREAMS=1 restores that behaviour for the A/B, profiles/r05_lane_modes.log)
+        if self.lanes > 1 and not os.environ.get("OTHELLO_BENCH_NEW_STREAMS"):
+            self.streams = pkg.engine.lane_streams(self.lanes, self.dev)
+        else:
+            self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.lanes)] if self.lanes > 1 else [None]
         # history ring per lane: room for the largest step target (+10 % rebalancing, + the games finishing while the
         # last rounds of a step are in flight) next to the games in flight
         per_lane = games // self.lanes

@@ -10,6 +10,12 @@ import os
 
 import numpy as np
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one taken by the default stream); multi-lane runs put one
+# stream per lane to work, and two lanes on one queue serialise their launches (four lanes: 25.7 k instead of 28 k games/s on
+# BASELINE configs[4], profiles/r05_hw_queues.log).  Read when the HIP runtime starts, so this only helps when the package is
+# imported before the first GPU call; a caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OTHELLO_MI355X_LIB: A/B-testing hook for kernel work (another build of the same library)
 LIB_PATH = os.environ.get("OTHELLO_MI355X_LIB") or os.path.join(_HERE, "libothello_mi355x.so")

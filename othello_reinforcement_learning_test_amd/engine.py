@@ -179,6 +179,25 @@ class HipResNetEvaluator:
             pass
 
 
+_LANE_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
+
+
+def lane_streams(n, device=None):
+    """The streams of the n lanes of a multi-lane run on `device`: made ONCE per process and device and reused by every run.
+
+    Not a micro-optimisation.  HIP maps streams onto a few hardware queues; with new streams per run the two streams of every
+    SECOND two-lane run of a process landed on ONE queue, their trunk launches alternated instead of overlapping and the run
+    lost 8-10 % (round 5: three identical two-lane legs in one process measured 1 682 / 1 518 / 1 675 games/s with new streams
+    per leg, 1 681 / 1 681 / 1 680 with these; profiles/r05_lane_modes.log).  The first streams of a process get distinct
+    queues, so the streams are created once and kept."""
+    import torch
+    dev = torch.cuda.current_device() if device is None else int(device)
+    pool = _LANE_STREAMS.setdefault(dev, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 def policy_from_visits(visits, self_b, opp_b, temperature, board_size=8):
     """MCTSNode.get_policy_distribution for a general temperature (/root/reference/src/mcts/node.py:162-182), the same
     numpy expressions in the same order on the root's children (= the legal moves in ascending order, or the pass):

@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from .engine import HipResNetEvaluator, SearchEngine
+from .engine import HipResNetEvaluator, SearchEngine, lane_streams
 from .self_play import tuples_from_arrays
 
 
@@ -156,13 +156,14 @@ class ParallelSelfPlayWorker:
         out = [None] * self.lanes
 
         dev = torch.cuda.current_device()
+        streams = lane_streams(self.lanes, dev)   # made once per process: new streams per call can share a hardware queue
 
         errors = []
 
         def run(k):
             try:
                 torch.cuda.set_device(dev)   # per-thread state: a new thread starts on device 0
-                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                with torch.cuda.stream(streams[k]):
                     eng = self._lane_engines[k]
                     n = eng.selfplay_run(shares[k], seed + 7919 * (k + 1), add_dirichlet_noise)
                     out[k] = eng.selfplay_fetch(n)[:3]

@@ -820,6 +820,26 @@ def test_bench_workload_rescues_across_lanes(pkg):
     assert w.counters() == ref.counters()
 
 
+def test_lane_streams_are_made_once(pkg):
+    """The lanes' streams are a per-process pool (engine.lane_streams), not new streams per run: with new ones the two streams
+    of every second two-lane run shared a hardware queue and the run lost 8-10 % (profiles/r05_lane_modes.log).  The multi-lane
+    worker and bench.py's Workload both draw from the pool."""
+    from othello_reinforcement_learning_test_amd.engine import lane_streams
+    a = lane_streams(2)
+    b = lane_streams(3)
+    assert a[0] is b[0] and a[1] is b[1] and len(b) == 3 and len({s.cuda_stream for s in b}) == 3
+    assert lane_streams(2)[1] is a[1]
+    torch.manual_seed(3)
+    net = pkg.OthelloResNet(2, 16).eval()
+    w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=4, num_parallel_games=16, lanes=2, verbose=False)
+    np.random.seed(1)
+    d1 = w.execute_episodes(12)
+    np.random.seed(1)
+    d2 = w.execute_episodes(12)                      # second call: the same two streams, the same tuples
+    assert len(d1) == len(d2) > 0 and all(np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(d1, d2))
+    assert lane_streams(2)[0] is a[0]
+
+
 def test_trunk_on_trained_like_weights(pkg):
     """fp16x3 trunk with non-trivial BatchNorm statistics, uneven per-channel scales and peaked policies (what a
     trained checkpoint looks like, unlike the seeded-random init): within 1e-4 of torch fp32 and no noisier
