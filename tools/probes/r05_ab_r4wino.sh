@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same-box A/B of this round's k_trunk_w (run-time activation scale) against round 4's: build/r4wino/libothello_mi355x.so = the
+# net_wino.hip of commit fa3db74 (plus the one-line helper wino_positions_per_workgroup) compiled with the product flags and linked
+# against the current objects.  -> profiles/r05_ab_r4wino.log (2.534 vs 2.538 ms per launch, 601 vs 602 games/s)
 set -e
 O=gpurun_out/r05; mkdir -p $O; L=$O/ab_r4wino.log; : > $L
 echo "== interleaved netbench: this round's k_trunk_w (run-time activation scale) vs round 4's (build/r4wino: fa3db74's net_wino.hip against the current library)" >> $L

@@ -5,7 +5,12 @@
 #   cache    slots / step / table size of the evaluation-cache leg            -> profiles/r05_sweep_cache.txt, _b.txt
 #   configs4 slots / lanes of the configs[4] leg                              -> profiles/r05_sweep_configs4_base.txt, _b.txt
 #   soak     parity sweep + full-size exact run on the final build            -> profiles/r05_parity_sweep.log, r05_fullsize_exact.log
-# usage (GPU box, repo root): bash tools/probes/r05_sweeps.sh probe|configs3|cache|configs4|soak
+#   lanes    three identical two-lane legs in one process, new streams per workload vs the per-process pool
+#                                                                             -> profiles/r05_lane_modes.log
+#   hwq      GPU_MAX_HW_QUEUES default (4) vs 8 on the legs and the headline; lane counts under 8 queues
+#                                                                             -> profiles/r05_hw_queues.log, r05_hw_queues_b.log
+#   cache2way  the two-way cache: its tests and a table-size sweep             -> profiles/r05_sweep_cache_2way.txt
+# usage (GPU box, repo root): bash tools/probes/r05_sweeps.sh probe|configs3|cache|configs4|soak|lanes|hwq|cache2way
 set -e
 O=gpurun_out/r05; mkdir -p $O
 case "$1" in
@@ -24,5 +29,31 @@ configs4)
 soak)
   python3 tools/parity_sweep.py > $O/parity_sweep.log 2>&1; tail -1 $O/parity_sweep.log
   python3 tools/fullsize_exact.py > $O/fullsize_exact.log 2>&1; tail -1 $O/fullsize_exact.log ;;
-*) echo "usage: $0 probe|configs3|cache|configs4|soak"; exit 2 ;;
+lanes)
+  L=$O/lane_modes.log; : > $L
+  echo "== three identical two-lane cache legs in ONE process, new streams per workload (behaviour up to round 5)" >> $L
+  OTHELLO_BENCH_NEW_STREAMS=1 timeout -k 10 300 python3 tools/leg_sweep.py cache 8192:2::3072::24 8192:2::3072::24 8192:2::3072::24 2>/dev/null | cut -c1-250 >> $L
+  echo "== the same with the lanes' streams made once per process" >> $L
+  timeout -k 10 300 python3 tools/leg_sweep.py cache 8192:2::3072::24 8192:2::3072::24 8192:2::3072::24 2>/dev/null | cut -c1-250 >> $L
+  cat $L ;;
+hwq)
+  L=$O/hw_queues.log; : > $L
+  for q in default 8; do
+    if [ $q = default ]; then export GPU_MAX_HW_QUEUES=4; else export GPU_MAX_HW_QUEUES=$q; fi   # (bench.py / the package default to 8 since round 5)
+    echo "== GPU_MAX_HW_QUEUES=$q: configs[4] 8960:4 twice, configs[3] 4608:3, headline 4096:2" >> $L
+    timeout -k 10 120 python3 tools/leg_sweep.py configs4 8960:4 8960:4 2>/dev/null | cut -c1-200 >> $L
+    timeout -k 10 200 python3 tools/leg_sweep.py configs3 4608:3::255 2>/dev/null | cut -c1-200 >> $L
+    timeout -k 10 120 python3 tools/leg_sweep.py headline 4096:2 2>/dev/null | cut -c1-200 >> $L
+  done
+  export GPU_MAX_HW_QUEUES=8; L2=$O/hw_queues_b.log; : > $L2
+  echo "== GPU_MAX_HW_QUEUES=8: configs[4] lanes" >> $L2
+  timeout -k 10 200 python3 tools/leg_sweep.py configs4 8960:4 11200:5 13440:6 8960:4 2>/dev/null | cut -c1-200 >> $L2
+  echo "== GPU_MAX_HW_QUEUES=8: headline lanes" >> $L2
+  timeout -k 10 300 python3 tools/leg_sweep.py headline 4096:2 4096:4 4098:3::1536 4096:2 2>/dev/null | cut -c1-200 >> $L2
+  cat $L $L2 ;;
+cache2way)
+  python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_selfplay_exact.py tests/test_gpu_multirank.py -m gpu -x -q -k "cache" 2>&1 | tail -3
+  timeout -k 10 500 python3 tools/leg_sweep.py cache 8192:2::3072::22 8192:2::3072::23 8192:2::3072::24 8192:2::3072::22 8192:2::3072::24 > $O/sweep_cache_2way.txt
+  cut -c1-120 $O/sweep_cache_2way.txt ;;
+*) echo "usage: $0 probe|configs3|cache|configs4|soak|lanes|hwq|cache2way"; exit 2 ;;
 esac
