@@ -45,7 +45,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; read when the HIP runtime starts
+# HSA_ENABLE_IPC_MODE_LEGACY=0 selects dmabuf IPC handles, the only kind this pool's host driver exports (with the legacy
+# mode RCCL's cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument`); read when the HIP runtime
+# starts.  A DEFAULT only: a caller's own value wins here AND in the self-launched ranks (launch_ranks passes the environment
+# on untouched), so an operator can flip it (it has never been exercised with N > 1 ranks).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them used by the default stream): with four lanes two
 # of them then share a queue and their launches serialise -- configs[4] on four lanes measured 25.7 k games/s with the default
 # and 27.9-28.1 k with 8 (profiles/r05_hw_queues.log; two- and three-lane workloads are unaffected).  Read when the runtime starts.
@@ -80,23 +84,24 @@ def mflop_per_position(blocks, filters, board=8):
 LEG_SECONDS = (("configs[3]", 67.0), ("configs[4]", 12.0), ("configs[1] + eval cache", 32.0))
 MEASURED_RATE = 615.0
 OTHER_LEGS_SECONDS = sum(s for _, s in LEG_SECONDS)
-LEGS_HARD_STOP = 530.0
+LEGS_HARD_STOP = 520.0
 DRIVER_LIMIT = 600.0
 
 
-def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_steps=1, cpu_budget=15.0,
+def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_steps=1, cpu_budget=20.0,
                     rate=PLANNING_RATE, startup=150.0, legs=True):
     """Wall-clock plan of one bench.py run on one MI355X (default workload): process start-up (the first
     `import torch` on a fresh box can take 2 minutes) + staggered ramp + (warmup + steps + profiled) steps +
-    the secondary legs that still fit (each scaled with the rate, admitted by the rule above) + CPU baseline (its budget
-    + the ply in flight when the budget ends, ~ 40 %)."""
+    the secondary legs that still fit (each scaled with the rate, admitted by the rule above) + CPU baseline."""
     ramp = 0.5 * slots * min(stagger, 61) / 61.0 / rate          # half-full slots during the staggered start
     t = startup + ramp + (warmup + steps + profile_steps) * step_games / rate
     for _, sec in (LEG_SECONDS if legs else ()):
         sec = sec * MEASURED_RATE / rate
         if t + 1.5 * sec <= LEGS_HARD_STOP:
             t += sec
-    return t + 1.4 * cpu_budget + 10.0
+    # CPU baseline: its budget + the ply in flight when the budget ends, or the 8 plies every stream must play (~5 s each on a
+    # loaded 128-core host) if that is longer
+    return t + max(1.4 * cpu_budget, 45.0) + 10.0
 
 
 TRUNK_SOURCES = ("net_wino.hip", "net_epilogue.h", "net_heads.h", "net.h", "Makefile")
@@ -146,13 +151,59 @@ def committed_traffic(kernel_name):
     return out
 
 
-def cpu_baseline(net, sims, budget_s, evals_per_game, min_plies=4):
+PHASE_BIN = 6   # plies per game-phase bin of the CPU baseline's estimator
+
+
+def seconds_per_game(phase, secs, plies_per_game=PLIES_PER_GAME, bin_plies=PHASE_BIN):
+    """Wall seconds ONE stream needs for one game, from sampled plies: mean ply time per game-phase bin (phase = plies played
+    before the ply; bins of `bin_plies`) summed over the phases 0 .. plies_per_game of a game.  An empty bin takes the mean of
+    its nearest non-empty neighbours.  Weighting by PHASE, not by plies finished: an endgame ply is cheap (many simulations
+    end in terminal nodes, no network evaluation), so a stream that started late finishes more plies inside a time budget
+    and a plain plies/s average over-weights it (VERDICT r5 weak #9)."""
+    import numpy as np
+    phase, secs = np.asarray(phase), np.asarray(secs, dtype=np.float64)
+    nb = int(np.ceil(plies_per_game / bin_plies))
+    idx = np.minimum(phase // bin_plies, nb - 1)
+    tot = np.bincount(idx, weights=secs, minlength=nb)[:nb]
+    cnt = np.bincount(idx, minlength=nb)[:nb]
+    mean = np.where(cnt > 0, tot / np.maximum(cnt, 1), np.nan)
+    if np.isnan(mean).all():
+        return float("nan")
+    have = np.flatnonzero(~np.isnan(mean))
+    for i in np.flatnonzero(np.isnan(mean)):
+        lo, hi = have[have < i], have[have > i]
+        near = [mean[lo[-1]]] if len(lo) else []
+        near += [mean[hi[0]]] if len(hi) else []
+        mean[i] = float(np.mean(near))
+    # plies of a game in each bin: bin_plies each, the last bin takes what is left of plies_per_game
+    w = np.full(nb, float(bin_plies))
+    w[-1] = plies_per_game - bin_plies * (nb - 1)
+    return float((mean * w).sum())
+
+
+def phase_weighted_rate(rec_phase, rec_secs, plies, cores, n_boot=2000, seed=1):
+    """-> (games/s of `cores` concurrent streams, (lo, hi) bootstrap 95 % interval over STREAMS).  rec_phase / rec_secs:
+    [streams, cap] per-ply records, plies[s] of them valid in row s."""
+    import numpy as np
+    rows = [(rec_phase[s, :plies[s]], rec_secs[s, :plies[s]]) for s in range(len(plies)) if plies[s] > 0]
+    est = lambda pick: cores / seconds_per_game(np.concatenate([rows[i][0] for i in pick]),   # noqa: E731
+                                                np.concatenate([rows[i][1] for i in pick]))
+    value = est(range(len(rows)))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    boot = np.array([est(rng.integers(0, len(rows), len(rows))) for _ in range(n_boot)])
+    boot = boot[np.isfinite(boot)]
+    return float(value), (float(np.percentile(boot, 2.5)), float(np.percentile(boot, 97.5)))
+
+
+def cpu_baseline(net, sims, budget_s, evals_per_game, min_plies=8):
     """Time the oracle (kind 'port') on the host: one serial self-play stream per PHYSICAL core of this process's affinity
     mask, stream s starting 58*s/streams random plies into a game (phase-uniform: openings, middle games and endgames are
     sampled like a whole game), each playing whole plies until `budget_s` seconds have passed and it has played at least
-    `min_plies` -- a bounded sample, with the spread of the per-stream rates reported beside the total.  (One stream per
-    hardware THREAD was measured and is slower: 256 streams on the box's 256 threads gave 0.32 games/s against 0.56-0.59 with
-    128 -- SMT siblings share the FMA units, and 256 private 12 MB weight sets thrash the last-level cache;
+    `min_plies` -- a bounded sample.  `value` weights the plies by GAME PHASE (seconds_per_game: mean ply time per 6-ply phase
+    bin, summed over a 60.7-ply game) and carries a bootstrap 95 % interval over the streams (`value_ci95`); the plain
+    plies-over-wall-clock figure of rounds 1-5 stays beside it as `value_unweighted`.  (One stream per hardware THREAD was
+    measured and is slower: 256 streams on the box's 256 threads gave 0.32 games/s against 0.56-0.59 with 128 -- SMT siblings
+    share the FMA units, and 256 private 12 MB weight sets thrash the last-level cache;
     profiles/r05_bench_driver_cmd_run1.json.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -173,27 +224,43 @@ def cpu_baseline(net, sims, budget_s, evals_per_game, min_plies=4):
     cfg = ol.SelfplayCfg(sims, 15, 1, 1.0, 0.3, 0.25, 1, 0)
     plies = np.zeros(cores, dtype=np.int32)
     secs = np.zeros(cores, dtype=np.float64)
+    cap = 256
+    rec_phase = np.zeros((cores, cap), dtype=np.int32)
+    rec_secs = np.zeros((cores, cap), dtype=np.float64)
+    rec_evals = np.zeros((cores, cap), dtype=np.int32)
     ev, th, ended = C.c_int64(0), C.c_int(0), C.c_int64(0)
+    i32p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_double)
     t0 = time.time()
-    n = ol.lib().orc_cpu_baseline_timed(onet.h, C.byref(cfg), cores, cores, int(min_plies), float(budget_s), 58, 42,
-                                        plies.ctypes.data_as(C.POINTER(C.c_int32)), secs.ctypes.data_as(C.POINTER(C.c_double)),
-                                        C.byref(ev), C.byref(th), C.byref(ended))
+    n = ol.lib().orc_cpu_baseline_phased(onet.h, C.byref(cfg), cores, cores, int(min_plies), float(budget_s), 58, 42,
+                                         plies.ctypes.data_as(i32p), secs.ctypes.data_as(f64p),
+                                         C.byref(ev), C.byref(th), C.byref(ended), cap, rec_phase.ctypes.data_as(i32p),
+                                         rec_secs.ctypes.data_as(f64p), rec_evals.ctypes.data_as(i32p))
     dt = time.time() - t0
+    kept = np.minimum(plies, cap)
+    value, (lo, hi) = phase_weighted_rate(rec_phase, rec_secs, kept, th.value)
     rate = plies / np.maximum(secs, 1e-9)            # plies/s of each stream on its own clock
+    spg = seconds_per_game(np.concatenate([rec_phase[s, :kept[s]] for s in range(cores)]),
+                           np.concatenate([rec_secs[s, :kept[s]] for s in range(cores)]))
     out = {
-        "value": round((n / PLIES_PER_GAME) / dt, 5), "unit": "games/s", "cores": th.value, "streams": cores,
+        "value": round(value, 5), "unit": "games/s", "cores": th.value, "streams": cores,
         "hardware_threads": hw_threads, "kind": "port",
+        "value_ci95": [round(lo, 5), round(hi, 5)],
+        "value_ci95_rel": round(max(value - lo, hi - value) / value, 4) if value > 0 else None,
+        "estimator": "cores / seconds-per-game, seconds-per-game = sum over the %.1f plies of a game of the mean ply time of the "
+                     "ply's %d-ply phase bin (%.1f s per game and stream here), so that cheap endgame plies are not over-"
+                     "weighted; interval: bootstrap over the %d streams (2000 resamples, 2.5 / 97.5 percentiles)"
+                     % (PLIES_PER_GAME, PHASE_BIN, spg, cores),
         "sample": "%d plies (%d network evals) of serial self-play, one stream per physical core (%d streams on %d OpenMP "
                   "threads), stream s starting 58*s/%d random plies into a game (phase-uniform: openings to endgames), %d-%d "
-                  "plies each (>= %d, until %.0f s had passed), %dx%d net fp32, %d sims/move, %.1f s of wall clock; scaled "
-                  "with %.1f plies/game (the engine's measured game length)"
+                  "plies each (>= %d, until %.0f s had passed), %dx%d net fp32, %d sims/move, %.1f s of wall clock"
                   % (n, ev.value, cores, th.value, cores, int(plies.min()), int(plies.max()), min_plies, budget_s,
-                     net.num_blocks, net.num_filters, sims, dt, PLIES_PER_GAME),
+                     net.num_blocks, net.num_filters, sims, dt),
         "evals_per_s": round(ev.value / dt, 1),
+        "value_unweighted": round((n / PLIES_PER_GAME) / dt, 5),
         "per_stream_plies_per_s": {"min": round(float(rate.min()), 4), "median": round(float(np.median(rate)), 4),
                                    "max": round(float(rate.max()), 4),
-                                   "note": "each stream's plies over its own busy time; value uses the total over the wall clock"},
-        "value_spread": [round(float(rate.min()) * cores / PLIES_PER_GAME, 5), round(float(rate.max()) * cores / PLIES_PER_GAME, 5)],
+                                   "note": "each stream's plies over its own busy time (late-starting streams play cheap endgame "
+                                           "plies: not an error band of `value`)"},
     }
     if evals_per_game:
         out["value_by_evals"] = round(ev.value / dt / evals_per_game, 5)
@@ -244,21 +311,9 @@ def proportional_shares(rates, nominal, lanes):
 
 
 def union_ms(spans):
-    """Total length of the union of (start, end) intervals (ms); `spans` = list of (n, 2) arrays."""
-    import numpy as np
-    spans = [s for s in spans if len(s)]
-    if not spans:
-        return 0.0
-    sp = np.concatenate(spans)
-    sp = sp[np.argsort(sp[:, 0])]
-    total, (cur_s, cur_e) = 0.0, sp[0]
-    for s_, e2 in sp[1:]:
-        if s_ > cur_e:
-            total += cur_e - cur_s
-            cur_s, cur_e = s_, e2
-        else:
-            cur_e = max(cur_e, e2)
-    return float(total + (cur_e - cur_s))
+    """Total length of the union of (start, end) intervals (ms); `spans` = list of (n, 2) arrays (engine.union_ms)."""
+    from othello_reinforcement_learning_test_amd.engine import union_ms as u
+    return u(spans)
 
 
 class Workload:
@@ -285,6 +340,10 @@ class Workload:
             self.streams = pkg.engine.lane_streams(self.lanes, self.dev)
         else:
             self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.lanes)] if self.lanes > 1 else [None]
+        # lane overlap is a checked property: measured on the first warm-up step (play(check=True)); a
+        # serialised arrangement is reported and the streams are drawn once more (engine.LaneOverlapCheck)
+        self.check = pkg.engine.LaneOverlapCheck(self.lanes, self.dev,
+                                                 max_redraws=int(os.environ.get("OTHELLO_LANE_REDRAWS", "1")))
         # history ring per lane: room for the largest step target (+10 % rebalancing, + the games finishing while the
         # last rounds of a step are in flight) next to the games in flight
         per_lane = games // self.lanes
@@ -319,8 +378,21 @@ class Workload:
             raise errors[0]
         return out
 
-    def play(self, target):
-        """One step's self-play: until >= target more games of this rank have finished -> (games, device tuple parts)."""
+    def play(self, target, check=False):
+        """One step's self-play: until >= target more games of this rank have finished -> (games, device tuple parts).
+        check=True (warm-up steps only): if the lane-overlap check is still pending, this step runs with the HIP-event hooks
+        on and decides it."""
+        measuring = check and self.check.pending
+        if measuring:
+            self.check.begin(self.engs)
+        try:
+            return self._play(target)
+        finally:
+            if measuring and self.check.end(self.engs):
+                self.torch.cuda.synchronize()      # the lanes move to other streams: nothing may be in flight on the old ones
+                self.streams = self.pkg.engine.lane_streams(self.lanes, self.dev)
+
+    def _play(self, target):
         # A launch of an fp16-split trunk that clamped an activation is never left standing (the reference's fp32 forward
         # has no clamp): every lane snapshots its stream before the step, and if the shared evaluator reports a clamp once
         # all lanes have joined it halves its activation scale and the step is replayed from the snapshots.  Seeded-random
@@ -396,7 +468,7 @@ def run_leg(pkg, torch, name, note="", board=8, blocks=10, filters=128, sims=50,
     w = Workload(pkg, torch, board, blocks, filters, sims, games, lanes, stagger, step_games, precision=None,
                  eval_cache=eval_cache, c_puct=c_puct, temp_threshold=temp_threshold)
     for _ in range(warmup):
-        w.play(step_games)
+        w.play(step_games, check=True)
     torch.cuda.synchronize()
     c0, t0, n = w.counters(), time.time(), 0
     cs0 = w.cache_stats() if eval_cache else None
@@ -426,7 +498,13 @@ def run_leg(pkg, torch, name, note="", board=8, blocks=10, filters=128, sims=50,
         "positions_per_launch": round(prof["evals"] / max(1, prof["net_launches"]), 1),
         "net_time_share": round(prof["union_ms"] * 1e-3 / prof["wall_s"], 4) if prof["wall_s"] > 0 else None,
         "tree_kernels_ms": round(prof["tree_ms"], 2),
+        # sum of the trunk launch durations / union of their intervals (profiled step): ~1 = the lanes' launches alternate
+        # (two streams on one hardware queue), -> lanes when every lane always has a launch running
+        "lanes_overlap": round(prof["net_ms"] / prof["union_ms"], 3) if prof["union_ms"] > 0 else None,
+        "lanes_check_warmup": w.check.report(),
     }
+    out["lanes_serialised"] = bool(lanes > 1 and out["lanes_overlap"] is not None and out["avg_launch_ms"] >=
+                                   pkg.engine.OVERLAP_MIN_LAUNCH_MS and out["lanes_overlap"] < pkg.engine.overlap_floor(lanes))
     if eval_cache:
         hits = st.get("cache_hits", 0)
         cst = {k: cs1[k] - cs0[k] for k in ("distinct_positions", "repeated_evals", "conflict_evictions")}
@@ -460,7 +538,11 @@ def launch_ranks(n_ranks, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     print("[bench] --gpus %d without WORLD_SIZE: starting %d ranks as a child: %s" % (n_ranks, n_ranks, " ".join(cmd[1:9])),
           file=sys.stderr, flush=True)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTHELLO_BENCH_SELF_LAUNCHED="1")
+    # the ranks inherit this process's environment as it is (HSA_ENABLE_IPC_MODE_LEGACY / GPU_MAX_HW_QUEUES: the caller's
+    # values, or the defaults set at the top of this file) -- nothing is forced, an operator can flip either knob
+    env = dict(os.environ, OTHELLO_BENCH_SELF_LAUNCHED="1")
+    print("[bench] ranks' environment: HSA_ENABLE_IPC_MODE_LEGACY=%s GPU_MAX_HW_QUEUES=%s"
+          % (env.get("HSA_ENABLE_IPC_MODE_LEGACY"), env.get("GPU_MAX_HW_QUEUES")), file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, env=env, start_new_session=True)   # own group: torchrun and its ranks end together
 
     def forward(signum, _frame):
@@ -498,11 +580,11 @@ def check_world(args, argv):
 
 
 def summarize_legs(other_configs):
-    """The secondary legs once more, compact: {configuration: [games/s, roofline frac, trunk share of the step]} (or "skipped" /
+    """The secondary legs once more, compact: {configuration: [games/s, roofline frac, trunk share of the step, lanes overlap]} (or "skipped" /
     "error").  The driver keeps the last 2 000 characters of stdout, and the full `other_configs` entries are longer than
     that, so this goes LAST in the JSON line (< 300 characters)."""
     short = {"configs[1] + eval cache": "configs[1]+cache"}
-    return {short.get(o["config"], o["config"]): ([o["value"], o["roofline_frac"], o["net_time_share"]] if "value" in o
+    return {short.get(o["config"], o["config"]): ([o["value"], o["roofline_frac"], o["net_time_share"], o.get("lanes_overlap")] if "value" in o
                                                   else ("skipped" if "skipped" in o else "error"))
             for o in other_configs}
 
@@ -543,9 +625,9 @@ def main():
                          "trunk launch duration over all launches of the run: the figure a rocprofv3 --kernel-trace "
                          "--stats of the same command must reproduce.  Not the headline configuration.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0,
+    ap.add_argument("--cpu-budget", type=float, default=20.0,
                     help="seconds of CPU work for the baseline (every stream plays whole plies until this much time has passed "
-                         "and it has played at least 4: ~20 s of wall clock)")
+                         "and it has played at least 8: ~35 s of wall clock at ~4 s per ply)")
     args = ap.parse_args()
     rc = check_world(args, sys.argv[1:])
     if rc is not None:
@@ -569,7 +651,8 @@ def main():
     try:
         pkg._lib.require_device()   # no GPU => fail loudly
     except Exception as exc:
-        raise SystemExit("bench.py rank %d/%d: %s" % (rank, world, exc))
+        raise SystemExit("bench.py rank %d/%d: %s [HSA_ENABLE_IPC_MODE_LEGACY=%s GPU_MAX_HW_QUEUES=%s]"
+                         % (rank, world, exc, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ.get("GPU_MAX_HW_QUEUES")))
     import torch.distributed as dist
     if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit("bench.py rank %d/%d: %d ranks need %d GPUs, this node shows %d (RCCL needs one GPU per rank; "
@@ -616,12 +699,13 @@ def main():
         shares[:] = proportional_shares(allr.cpu().numpy(), nominal, lanes)
 
     xchg = {"s": 0.0, "n": 0}   # time of the exchange step inside the timed region (this rank)
+    state = {"warming": True}   # warm-up steps may run the lane-overlap check (hooks on); timed steps never do
 
     def step():
         """-> (games this rank finished, replay samples of the whole job after the exchange)"""
         mine = shares[rank]
         t_play = time.time()
-        games, parts = wl.play(mine)
+        games, parts = wl.play(mine, check=state["warming"])
         t_play = time.time() - t_play
         if use_dist:   # the one exchange step: RCCL all-gather of the replay tuples
             t_x = time.time()
@@ -656,6 +740,7 @@ def main():
         g, _ = step()
         tally_launches()
         beat("warm-up step %d/%d: %d games in %.2f s" % (i + 1, args.warmup, g, time.time() - t1))
+    state["warming"] = False
     barrier()
     c0 = counters()
     xchg["s"], xchg["n"] = 0.0, 0
@@ -702,6 +787,19 @@ def main():
         beat("profiled step: %d games in %.2f s, %d trunk launches, busy %.0f ms"
              % (prof["games"], prof["wall_s"], prof["net_launches"], prof["union_ms"]))
     ev.check_saturation()   # the clamp of the fp16-split trunk, surfaced: never a silent deviation from the reference
+    # lane overlap of THIS rank in the profiled step (sum of the trunk launch durations / union of their intervals) and its
+    # mean launch duration, gathered so that a slow rank of an N > 1 job is attributable: a longer launch = a lower clock,
+    # a lower overlap = lanes sharing a hardware queue
+    my_overlap = prof["net_ms"] / prof["union_ms"] if prof["union_ms"] > 0 else 0.0
+    my_launch_ms = prof["net_ms"] / max(1, prof["net_launches"])
+    per_rank_overlap, per_rank_launch_ms = [round(my_overlap, 3)], [round(my_launch_ms, 4)]
+    if use_dist:
+        t = torch.tensor([my_overlap, my_launch_ms], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        allo = torch.zeros(2 * world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allo, t)
+        allo = allo.cpu().view(world, 2)
+        per_rank_overlap = [round(float(allo[r, 0]), 3) for r in range(world)]
+        per_rank_launch_ms = [round(float(allo[r, 1]), 4) for r in range(world)]
 
     if rank == 0:
         # With one lane the union equals the sum of the launch durations; with several lanes the launches of the
@@ -727,7 +825,11 @@ def main():
             "backend": ("none (single process)" if not use_dist else
                         ("gloo (REHEARSAL on host copies)" if gloo else "nccl (= RCCL)")),
             "per_rank_games_per_s": per_rank_rate,
+            "per_rank_lanes_overlap": per_rank_overlap,
+            "per_rank_avg_launch_ms": per_rank_launch_ms,
             "exchange_ms_per_step": exchange_ms,
+            # the runtime knobs the multi-lane / multi-rank paths depend on, as this rank saw them
+            "runtime_env": pkg._lib.runtime_env(),
             "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("OTHELLO_BENCH_SELF_LAUNCHED")
                             else ("torch.distributed.run of the caller" if "RANK" in os.environ else "single process")),
             "steps": args.steps,
@@ -790,6 +892,12 @@ def main():
                                                if args.hooks_always else None),
                 "launches_all": all_launch["n"] if args.hooks_always else None,
                 "busy_ms": round(prof["union_ms"], 1), "concurrent_lanes": lanes,
+                # sum of the launch durations / union of their intervals: ~1 = the lanes' launches alternate (two streams on
+                # one hardware queue: -8...-10 %), -> lanes when every lane always has a launch running
+                "lanes_overlap": round(my_overlap, 3),
+                "lanes_serialised": bool(lanes > 1 and my_launch_ms >= pkg.engine.OVERLAP_MIN_LAUNCH_MS
+                                         and my_overlap < pkg.engine.overlap_floor(lanes)),
+                "lanes_check_warmup": wl.check.report(),
                 "time_basis": "union of the HIP-event intervals of all k_trunk launches (the %d lanes' launches "
                               "overlap; sum of launch durations = %.0f ms)" % (lanes, prof["net_ms"]),
                 "positions_per_launch": round(prof["evals"] / max(1, prof["net_launches"]), 1),

@@ -1108,14 +1108,18 @@ int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg,
     if (games_ended) *games_ended = ended;
     return total;
 }
-/* Time-bounded form of the phase-uniform baseline (round 5: every hardware thread, a per-stream spread): `streams` serial
+/* (round 6: orc_cpu_baseline_phased also records, per stream and ply -- rec_cap rows per stream -- the ply's PHASE (plies played
+ * before it), its wall time and its network evaluations, so that bench.py can weight the plies by game phase: endgame plies are
+ * cheap (many simulations end in terminal nodes) and a stream that started late finishes more of them inside the budget.)
+ * Time-bounded form of the phase-uniform baseline (round 5: every hardware thread, a per-stream spread): `streams` serial
  * self-play streams on `threads` OpenMP threads (0: the runtime's default), stream s starting (s * spread) / streams random
  * plies into a game; each stream plays whole plies (self_play.py:80-117) until `budget_s` seconds have passed since the
  * parallel region began AND it has played at least `min_plies`.  plies_out[s] / secs_out[s] (either may be NULL): what
  * stream s played and how long its timed plies took (its own clock, the random prefix excluded).  Returns total plies. */
-int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
-                               double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
-                               int64_t *n_evals, int *threads_used, int64_t *games_ended) {
+int64_t orc_cpu_baseline_phased(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
+                                double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
+                                int64_t *n_evals, int *threads_used, int64_t *games_ended, int rec_cap, int32_t *rec_phase,
+                                double *rec_secs, int32_t *rec_evals) {
     int64_t total = 0, evals = 0, ended = 0;
     int nt = 1;
 #ifdef _OPENMP
@@ -1163,9 +1167,24 @@ int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, 
                 double temp = b.move_count < cfg->temperature_threshold ? 1.0 : 0.0;
                 orc_search_cfg sc = {cfg->num_simulations, cfg->c_puct, cfg->dirichlet_alpha, cfg->dirichlet_epsilon,
                                      temp, cfg->add_noise};
+#ifdef _OPENMP
+                const double tp = omp_get_wtime();
+#endif
+                const int64_t e0 = cc.evals;
+                const int phase = b.move_count;
                 orc_search(&b, &sc, counting_eval, &cc, &r, pi, NULL, NULL, NULL);
                 int a = temp == 0 ? argmax65(pi) : r.choice(r.ctx, pi);
                 orc_make_move(&b, a);
+                if (rec_cap > 0 && done < rec_cap) { /* the ply's phase (plies played before it), its time and evaluations */
+                    const int64_t at = (int64_t)s * rec_cap + done;
+                    if (rec_phase) rec_phase[at] = phase;
+                    if (rec_evals) rec_evals[at] = (int32_t)(cc.evals - e0);
+#ifdef _OPENMP
+                    if (rec_secs) rec_secs[at] = omp_get_wtime() - tp;
+#else
+                    if (rec_secs) rec_secs[at] = 0.0;
+#endif
+                }
                 ++done;
                 ++total;
             }
@@ -1182,5 +1201,11 @@ int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, 
     if (threads_used) *threads_used = nt;
     if (games_ended) *games_ended = ended;
     return total;
+}
+int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
+                               double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
+                               int64_t *n_evals, int *threads_used, int64_t *games_ended) {
+    return orc_cpu_baseline_phased(net, cfg, streams, threads, min_plies, budget_s, spread, seed, plies_out, secs_out, n_evals,
+                                   threads_used, games_ended, 0, NULL, NULL, NULL);
 }
 #endif /* ORC_N == 8 */

@@ -131,6 +131,10 @@ int64_t orc_cpu_baseline_spread(const orc_net *net, const orc_selfplay_cfg *cfg,
                                 int spread, uint64_t seed, int64_t *n_evals, int *threads_used, int64_t *games_ended);
 
 /* time-bounded form with a per-stream report (bench.py's cpu_baseline since round 5): see othello_oracle.c */
+int64_t orc_cpu_baseline_phased(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
+                                double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
+                                int64_t *n_evals, int *threads_used, int64_t *games_ended, int rec_cap, int32_t *rec_phase,
+                                double *rec_secs, int32_t *rec_evals);
 int64_t orc_cpu_baseline_timed(const orc_net *net, const orc_selfplay_cfg *cfg, int streams, int threads, int min_plies,
                                double budget_s, int spread, uint64_t seed, int32_t *plies_out, double *secs_out,
                                int64_t *n_evals, int *threads_used, int64_t *games_ended);

@@ -14,7 +14,32 @@ import numpy as np
 # stream per lane to work, and two lanes on one queue serialise their launches (four lanes: 25.7 k instead of 28 k games/s on
 # BASELINE configs[4], profiles/r05_hw_queues.log).  Read when the HIP runtime starts, so this only helps when the package is
 # imported before the first GPU call; a caller's own setting wins.
+def _hip_runtime_up():
+    """True when this process had already started the HIP runtime through torch when the package was imported (the one case
+    this module can see; a HIP call made by other native code before the import is invisible to it)."""
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# What the two runtime knobs were when the package was imported, for the operator and for bench.py's JSON line
+# (`runtime_env`): GPU_MAX_HW_QUEUES as the caller had it (None = unset, this module then sets 8) and whether the HIP runtime was
+# already up -- in which case the setting below comes too late and lanes > 3 share hardware queues (lane_overlap_check warns).
+RUNTIME_AT_IMPORT = {"GPU_MAX_HW_QUEUES_from_caller": os.environ.get("GPU_MAX_HW_QUEUES"),
+                     "hip_runtime_up_before_import": _hip_runtime_up()}
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def runtime_env():
+    """The effective values of the environment knobs the multi-lane / multi-rank paths depend on."""
+    return {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "GPU_MAX_HW_QUEUES_set_by": ("caller" if RUNTIME_AT_IMPORT["GPU_MAX_HW_QUEUES_from_caller"] is not None
+                                         else "package default (8)"),
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "package_imported_before_hip_runtime": not RUNTIME_AT_IMPORT["hip_runtime_up_before_import"]}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OTHELLO_MI355X_LIB: A/B-testing hook for kernel work (another build of the same library)

@@ -294,18 +294,24 @@ __global__ __launch_bounds__(256) void k_cache_insert(Dev d, const float* __rest
         unsigned long long* st = d.cstat + (size_t)blockIdx.x * 4;
         atomicAdd(&st[seen ? 1 : 0], 1ULL);
         // the way to write: the position's own entry if it is there already (evaluated twice since the clear: refresh it), an
-        // empty way, else the way inserted longer ago; if another wave claimed that way in THIS launch, the other way; if
-        // that is taken too, the result is not cached (it was evaluated anyway)
+        // empty way, else the way inserted longer ago; if another wave claimed that (empty / older) way in THIS launch, the
+        // other way; if that is taken too, the result is not cached (it was evaluated anyway)
         const ulonglong2 ka = *(const ulonglong2*)(d.ck + 2 * (size_t)cs), kb = *(const ulonglong2*)(d.ck + 2 * (size_t)cs + 2);
         const bool ea = ka.x == ~0ULL && ka.y == ~0ULL, eb = kb.x == ~0ULL && kb.y == ~0ULL;
         int first;
+        bool by_key = true;
         if (ka.x == sb && ka.y == ob) first = 0;
         else if (kb.x == sb && kb.y == ob) first = 1;
-        else if (ea || eb) first = ea ? 0 : 1;
-        else first = d.clk[cs] <= d.clk[cs + 1] ? 0 : 1;
+        else {
+            by_key = false;
+            if (ea || eb) first = ea ? 0 : 1;
+            else first = d.clk[cs] <= d.clk[cs + 1] ? 0 : 1;
+        }
         int way = first;
         own = atomicMax(&d.clk[cs + way], d.cepoch) < d.cepoch;  // first claimant of this entry in this launch
-        if (!own) {
+        // the position's OWN entry already claimed in this launch (another wave of the same position): nothing to do -- the other
+        // way belongs to another position and must not be evicted for a duplicate of this key
+        if (!own && !by_key) {
             way = first ^ 1;
             own = atomicMax(&d.clk[cs + way], d.cepoch) < d.cepoch;
         }

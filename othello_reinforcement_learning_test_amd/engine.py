@@ -18,6 +18,31 @@ def default_precision(num_filters, board_size=8):
     return "f16x3" if num_filters in (32, 64) else "f32"
 
 
+_PROBE = {}   # board size -> (self, opp, legal) uint64 arrays
+
+
+def probe_positions(board_size=8, n=256):
+    """A fixed set of n positions of seeded random games (its own numpy Generator: the global RNG the workers draw their seeds
+    from is not touched), played with the library's host rules: what HipResNetEvaluator.refresh() evaluates once after a weight
+    update to choose the activation scale as a function of the WEIGHTS (see refresh)."""
+    got = _PROBE.get((board_size, n))
+    if got is None:
+        lib = _lib.load()
+        rng = np.random.Generator(np.random.PCG64(20240607 + board_size))
+        pos = []
+        while len(pos) < n:
+            b = _lib.Board()
+            lib.oth_board_reset_n(board_size, C.byref(b))
+            while not lib.oth_board_is_terminal_n(board_size, C.byref(b)) and len(pos) < n:
+                legal = int(lib.oth_legal_moves_n(board_size, b.self_board, b.opp_board))
+                pos.append((b.self_board, b.opp_board, legal))
+                moves = [a for a in range(board_size * board_size) if (legal >> a) & 1] or [board_size * board_size]
+                lib.oth_board_make_move_n(board_size, C.byref(b), int(moves[int(rng.integers(len(moves)))]))
+        got = tuple(np.array([p[j] for p in pos], dtype=np.uint64) for j in range(3))
+        _PROBE[(board_size, n)] = got
+    return got
+
+
 class HipResNetEvaluator:
     """OthelloResNet forward (reference net.py:182-205, eval mode) on the GPU.
 
@@ -36,6 +61,7 @@ class HipResNetEvaluator:
         self.board_size = board_size
         self.policy_size = board_size * board_size + 1
         self.precision = precision or default_precision(self.num_filters, board_size)
+        self._precision0 = self.precision   # what a weight update goes back to (a rescue may have switched to "f32")
         if self.precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self._h = _lib.load().oth_net_create(self.num_blocks, self.num_filters, board_size)
@@ -53,13 +79,34 @@ class HipResNetEvaluator:
         return v
 
     def refresh(self, force=False):
-        """Re-upload (fold + repack) the weights if the model changed since the last call."""
+        """Re-upload (fold + repack) the weights if the model changed since the last call.
+
+        A weight UPDATE (the version counters moved since the last upload: the trainer stepped, trainer.py:283-328) also
+        forgets what earlier weights did to the activation scale and the precision (the scale used to be sticky,
+        so results depended on the process's history): both go back to their starting values (16, the constructor's
+        precision), the new weights are uploaded, and ONE launch over a fixed set of 256 probe positions (probe_positions)
+        lets the rescue lower the scale again if these weights need it -- so the scale a call runs at is a function of the
+        weights (and, only if a position outside the probe set saturates later, of that call).  No launch of this network
+        may be in flight (the workers call refresh() at the start of a call)."""
         ver = self._model_version()
+        moved = self._version is not None and ver != self._version
         if force or ver != self._version:
+            if moved and not force and self._precision0 != "f32":
+                self.precision = self._precision0
+                _lib.call("oth_net_set_act_scale", self._h, C.c_float(16.0))
             blob = _lib.state_dict_blob(self.model.state_dict())
             _lib.call("oth_net_load_state", self._h, _lib.np_ptr(blob, C.c_float), blob.size,
                       _lib.PRECISIONS[self.precision])
             self._version = ver
+            if moved and not force and self.precision != "f32":
+                self.calibrate()
+
+    def calibrate(self):
+        """One rescued launch over the probe positions: -> the activation scale these weights run at."""
+        import torch
+        sb, ob, lg = (torch.from_numpy(a.view(np.int64)).cuda() for a in probe_positions(self.board_size))
+        self.forward_bits(sb, ob, lg, rescue=True)
+        return self.act_scale
 
     @property
     def handle(self):
@@ -69,8 +116,11 @@ class HipResNetEvaluator:
         """x: CUDA float32 (N,3,S,S) of 0/1 planes -> (log-probs (N,S*S+1), value (N,1)) CUDA tensors.
 
         ``rescue=True`` (default): an fp16-split launch that clamped an activation is run again at a lower activation
-        scale (``needs_rescue``; the check synchronises the stream).  ``rescue=False`` launches once, asynchronously,
-        and leaves the device flag for the caller (``saturated`` / ``check_saturation``)."""
+        scale (``needs_rescue``).  THE CHECK SYNCHRONISES: every call then ends with a 4-byte device-to-host copy and a
+        hipStreamSynchronize, i.e. host and device meet once per call -- right for a caller that reads the outputs next
+        (``.cpu()`` synchronises anyway), wrong inside a pipeline of launches.  ``rescue=False`` launches once,
+        ASYNCHRONOUSLY, and leaves the device flag for the caller to collect at its own join point (``needs_rescue`` and
+        run the work again, or ``check_saturation`` to fail loudly) -- what the workers and the engine do."""
         import torch
         x = x.contiguous()
         n = x.shape[0]
@@ -179,23 +229,181 @@ class HipResNetEvaluator:
             pass
 
 
-_LANE_STREAMS = {}   # device index -> [torch.cuda.Stream, ...]
+_LANE_STREAMS = {}   # device index -> {"pool": [torch.cuda.Stream, ...], "start": index of the first stream in use}
 
 
-def lane_streams(n, device=None):
+def lane_streams(n, device=None, redraw=False):
     """The streams of the n lanes of a multi-lane run on `device`: made ONCE per process and device and reused by every run.
 
     Not a micro-optimisation.  HIP maps streams onto a few hardware queues; with new streams per run the two streams of every
     SECOND two-lane run of a process landed on ONE queue, their trunk launches alternated instead of overlapping and the run
     lost 8-10 % (round 5: three identical two-lane legs in one process measured 1 682 / 1 518 / 1 675 games/s with new streams
     per leg, 1 681 / 1 681 / 1 680 with these; profiles/r05_lane_modes.log).  The first streams of a process get distinct
-    queues, so the streams are created once and kept."""
+    queues, so the streams are created once and kept.
+
+    ``redraw=True`` (what lane_overlap_check does when it finds the lanes serialised): n NEW streams are appended to the pool
+    and become the arrangement every later call returns (``lane_streams_select`` goes back to an earlier one).
+
+    One multi-lane worker at a time per device: every worker of the process is handed these same streams, so two multi-lane
+    workers driven concurrently from two host threads would share them and serialise."""
     import torch
     dev = torch.cuda.current_device() if device is None else int(device)
-    pool = _LANE_STREAMS.setdefault(dev, [])
-    while len(pool) < n:
+    ent = _LANE_STREAMS.setdefault(dev, {"pool": [], "start": 0})
+    if redraw:
+        ent["start"] = len(ent["pool"])
+    pool, start = ent["pool"], ent["start"]
+    while len(pool) < start + n:
         pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
+    return pool[start:start + n]
+
+
+def lane_streams_select(start, device=None):
+    """Make the arrangement that begins at pool index `start` the current one (after a redraw that did not help);
+    -> the previous start."""
+    import torch
+    dev = torch.cuda.current_device() if device is None else int(device)
+    ent = _LANE_STREAMS.setdefault(dev, {"pool": [], "start": 0})
+    old, ent["start"] = ent["start"], int(start)
+    return old
+
+
+def lane_streams_start(device=None):
+    import torch
+    dev = torch.cuda.current_device() if device is None else int(device)
+    return _LANE_STREAMS.setdefault(dev, {"pool": [], "start": 0})["start"]
+
+
+def union_ms(spans):
+    """Total length of the union of (start, end) intervals (ms); `spans` = list of (n, 2) arrays."""
+    spans = [s for s in spans if len(s)]
+    if not spans:
+        return 0.0
+    sp = np.concatenate(spans)
+    sp = sp[np.argsort(sp[:, 0])]
+    total, (cur_s, cur_e) = 0.0, sp[0]
+    for s_, e2 in sp[1:]:
+        if s_ > cur_e:
+            total += cur_e - cur_s
+            cur_s, cur_e = s_, e2
+        else:
+            cur_e = max(cur_e, e2)
+    return float(total + (cur_e - cur_s))
+
+
+# Below these a multi-lane run counts as SERIALISED (its lanes' network launches alternate instead of overlapping -- two
+# streams on one hardware queue, DESIGN section 5): sum of launch durations / union of their intervals.  Measured on MI355X
+# (profiles/r06_lane_overlap.log): two lanes 1.8 on separate queues and 1.0 on one stream.  The floor grows with the lane
+# count (1 + 0.3 per extra lane: 1.3 / 1.6 / 1.9) because with four lanes on four of which two share a queue the figure only
+# drops to ~2.  Launches shorter than MIN_LAUNCH_MS are launch-bound (toy networks): the host cannot keep two queues fed,
+# the ratio says nothing about the queues and nothing is flagged.
+OVERLAP_MIN_LAUNCH_MS = 0.25
+
+
+def overlap_floor(lanes):
+    return 1.0 + 0.3 * (max(1, int(lanes)) - 1)
+
+
+def lanes_overlap(engines):
+    """-> dict(overlap, sum_ms, union_ms, launches, mean_launch_ms, lanes, serialised) from the HIP-event spans the engines
+    recorded during their last run / step (SearchEngine.set_timing(True) before it).  overlap = sum of the network launch
+    durations / union of their intervals on the process-wide time axis: ~1 when the lanes' launches alternate, -> the lane
+    count when every lane always has a launch running."""
+    spans = [e.net_spans() for e in engines]
+    tot = float(sum(float((s[:, 1] - s[:, 0]).sum()) for s in spans if len(s)))
+    n = int(sum(len(s) for s in spans))
+    uni = union_ms(spans)
+    ov = tot / uni if uni > 0 else 0.0
+    mean = tot / n if n else 0.0
+    lanes = len(engines)
+    return {"overlap": round(ov, 3), "sum_ms": round(tot, 2), "union_ms": round(uni, 2), "launches": n,
+            "mean_launch_ms": round(mean, 4), "lanes": lanes, "floor": overlap_floor(lanes),
+            "serialised": bool(lanes > 1 and n >= 8 * lanes and mean >= OVERLAP_MIN_LAUNCH_MS and ov < overlap_floor(lanes))}
+
+
+_WARNED = set()
+
+
+def warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+class LaneOverlapCheck:
+    """Lane overlap as a CHECKED property of a multi-lane run (bench.py's Workload, ParallelSelfPlayWorker with lanes > 1).
+
+    Protocol: ``begin(engines)`` before a run / step turns the HIP-event hooks of the engines on; ``end(engines)`` after it
+    turns them off, computes ``lanes_overlap`` and decides: a serialised run is reported once on stderr (RuntimeWarning),
+    and -- while redraws are left -- the lanes' streams are drawn once more from a widened pool (``lane_streams(redraw=
+    True)``) so that the caller's NEXT run is measured on the new arrangement; the better of the arrangements seen is kept.
+    ``pending`` says whether the next run should be measured too.  ``report()`` -> what bench.py / last_stats print."""
+
+    def __init__(self, lanes, device=None, max_redraws=1):
+        self.lanes, self.device = int(lanes), device
+        self.max_redraws = int(max_redraws)
+        self.history = []            # [(pool start, lanes_overlap dict)]
+        self.pending = self.lanes > 1
+        self.redraws = 0
+        self.kept = None
+        self._was = []
+        at = _lib.RUNTIME_AT_IMPORT
+        if self.lanes > 3 and at["hip_runtime_up_before_import"] and at["GPU_MAX_HW_QUEUES_from_caller"] is None:
+            warn_once("late-queues", "%d lanes, but the HIP runtime was started before this package was imported, so its "
+                      "GPU_MAX_HW_QUEUES=8 default has no effect (HIP's own default is 4 hardware queues, one of them the "
+                      "default stream's): two lanes will share a queue and serialise (-8 %% measured on BASELINE configs[4]).  "
+                      "Import the package, or set GPU_MAX_HW_QUEUES=8, before the first GPU call" % self.lanes)
+
+    def begin(self, engines):
+        self._was = [e.timing for e in engines]
+        for e in engines:
+            e.set_timing(True)
+
+    def end(self, engines):
+        """-> True when the caller must fetch its streams again (lane_streams) before the next run."""
+        m = lanes_overlap(engines)
+        for e, was in zip(engines, self._was):
+            e.set_timing(was)
+        start = lane_streams_start(self.device)
+        self.history.append((start, m))
+        self.pending = False
+        if not m["serialised"]:
+            if self.kept is None:
+                self.kept = len(self.history) - 1
+            elif m["overlap"] > self.history[self.kept][1]["overlap"]:
+                self.kept = len(self.history) - 1
+            if self.kept != len(self.history) - 1:
+                lane_streams_select(self.history[self.kept][0], self.device)
+                return True
+            return False
+        late = _lib.RUNTIME_AT_IMPORT["hip_runtime_up_before_import"] and \
+            _lib.RUNTIME_AT_IMPORT["GPU_MAX_HW_QUEUES_from_caller"] is None
+        warn_once(("serialised", self.lanes),
+                  "the %d lanes' network launches do not overlap (sum / union of the launch intervals %.2f, expected >= %.1f; "
+                  "mean launch %.2f ms): their streams share a hardware queue and the run loses 8-10 %%.  GPU_MAX_HW_QUEUES=%s%s"
+                  % (self.lanes, m["overlap"], m["floor"], m["mean_launch_ms"], _lib.runtime_env()["GPU_MAX_HW_QUEUES"],
+                     " was set by this package AFTER the HIP runtime had started, so it has no effect: import the package (or "
+                     "set GPU_MAX_HW_QUEUES=8) before the first GPU call" if late else ""))
+        if self.redraws < self.max_redraws:
+            self.redraws += 1
+            lane_streams(self.lanes, self.device, redraw=True)
+            self.pending = True
+            return True
+        # out of redraws: keep the best arrangement seen
+        best = max(range(len(self.history)), key=lambda i: self.history[i][1]["overlap"])
+        self.kept = best
+        if self.history[best][0] != start:
+            lane_streams_select(self.history[best][0], self.device)
+            return True
+        return False
+
+    def report(self):
+        if not self.history:
+            return {"lanes_overlap": None, "lanes_serialised": None}
+        kept = self.history[self.kept if self.kept is not None else -1][1]
+        return {"lanes_overlap": kept["overlap"], "lanes_serialised": kept["serialised"], "floor": kept["floor"],
+                "mean_launch_ms": kept["mean_launch_ms"], "stream_redraws": self.redraws,
+                "arrangements_tried": [h[1]["overlap"] for h in self.history]}
 
 
 def policy_from_visits(visits, self_b, opp_b, temperature, board_size=8):
@@ -462,8 +670,11 @@ class SearchEngine:
         _lib.call("oth_engine_cache_stats", self._h, out, _lib.current_stream())
         return dict(zip(("distinct_positions", "repeated_evals", "conflict_evictions", "entries"), list(out)))
 
+    timing = False   # HIP-event hooks on every launch (set_timing)
+
     def set_timing(self, enable=True):
         _lib.call("oth_engine_set_timing", self._h, 1 if enable else 0)
+        self.timing = bool(enable)
 
     def net_spans(self):
         """(n, 2) array of (start, end) ms of every network launch of the last run on a process-wide time axis

@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from .engine import HipResNetEvaluator, SearchEngine, lane_streams
+from .engine import HipResNetEvaluator, LaneOverlapCheck, SearchEngine, lane_streams
 from .self_play import tuples_from_arrays
 
 
@@ -125,6 +125,10 @@ class ParallelSelfPlayWorker:
             raise ValueError("continuous=True needs rng_mode='device'")
         self.last_stats = {}
         self._ran = [self.engine]   # engines the last device-RNG call ran on
+        # lanes > 1: whether the lanes' network launches really overlap is CHECKED on the first multi-lane call (HIP-event hooks
+        # on for that call; engine.LaneOverlapCheck): a serialised arrangement (two streams on one hardware queue, -8...-10 %)
+        # is announced once and the streams are drawn again for the next call
+        self._lane_check = None
 
     # ---- device RNG: whole call on the GPU, finished slots refilled -------------------------
     def _grow_engine(self, num_episodes):
@@ -157,6 +161,11 @@ class ParallelSelfPlayWorker:
 
         dev = torch.cuda.current_device()
         streams = lane_streams(self.lanes, dev)   # made once per process: new streams per call can share a hardware queue
+        if self._lane_check is None:
+            self._lane_check = LaneOverlapCheck(self.lanes, dev)
+        measuring = self._lane_check.pending
+        if measuring:
+            self._lane_check.begin(self._lane_engines)
 
         errors = []
 
@@ -181,6 +190,8 @@ class ParallelSelfPlayWorker:
             # joined (no launch in flight), and every lane then restarts from its seed
             if not self.batch_mcts.evaluator.needs_rescue():
                 break
+        if measuring:
+            self._lane_check.end(self._lane_engines)   # (the next call fetches its streams anew)
         return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
 
     def _run_stream(self, num_episodes):
@@ -269,6 +280,12 @@ class ParallelSelfPlayWorker:
             for k, v in eng.counters().items():
                 counters[k] = counters.get(k, 0) + v
         games = len(self.last_game_ids) if (self.continuous and self.rng_mode == "device") else num_episodes
+        ev = self.batch_mcts.evaluator
+        # what the run's arithmetic was: the activation scale of the fp16-split trunk and every rescue so far
+        counters.update({"precision": getattr(ev, "precision", None), "act_scale": getattr(ev, "act_scale", None),
+                         "rescues": len(getattr(ev, "rescues", ()))})
+        if self._lane_check is not None and self._ran is self._lane_engines:
+            counters.update(self._lane_check.report())
         # the engine's counters are cumulative ("games" = every game finished so far): kept under "engine_*" names
         self.last_stats = {**{"engine_" + k if k == "games" else k: v for k, v in counters.items()},
                            "games": games, "samples": len(data), "seconds": dt,
@@ -297,6 +314,19 @@ def create_parallel_self_play_worker(config, model, device=None, **kwargs):
     from .bitboard import OthelloBitboard
     mcts = config.get("mcts", {})
     sp = config.get("self_play", {})
+    # `self_play.continuous: true` -- a key of THIS package, absent from the reference's YAML files (absent = off = the
+    # reference's call-by-call behaviour): the worker's slots keep playing between execute_episodes calls, so a trainer that
+    # asks for 100 episodes per iteration (configs/fast_8x8.yaml) is served from full slots instead of a ragged 100-game batch
+    # (INTEGRATION.md section 1 has the rates); the one semantic difference is that a game may span a weight update.
+    # `self_play.stagger_rounds` spreads the slots' start over that many ply rounds.  A keyword argument of the same name wins.
+    if "continuous" in sp:
+        kwargs.setdefault("continuous", bool(sp["continuous"]))
+    if "stagger_rounds" in sp:
+        kwargs.setdefault("stagger_rounds", int(sp["stagger_rounds"]))
+    # `self_play.device_slots`: game slots on the device (default: as many as a call has episodes, see __init__).  In continuous
+    # mode it is the number of games in flight: a game then spans about device_slots / num_episodes weight updates.
+    if "device_slots" in sp:
+        kwargs.setdefault("device_slots", int(sp["device_slots"]))
     return ParallelSelfPlayWorker(
         board_class=OthelloBitboard,
         model=model,

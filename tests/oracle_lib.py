@@ -123,6 +123,9 @@ def lib():
         L.orc_cpu_baseline_timed.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                              C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                              C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.orc_cpu_baseline_phased.restype = C.c_int64
+        L.orc_cpu_baseline_phased.argtypes = L.orc_cpu_baseline_timed.argtypes + [C.c_int, C.POINTER(C.c_int32),
+                                                                                  C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.orc_cpu_baseline_spread.restype = C.c_int64
         L.orc_cpu_baseline_spread.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg), C.c_int, C.c_int, C.c_int,
                                               C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int),

@@ -44,6 +44,28 @@ def test_plain_gpus_n_launches_its_own_ranks_and_relays_their_exit_code():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_callers_ipc_mode_reaches_the_self_launched_ranks():
+    """HSA_ENABLE_IPC_MODE_LEGACY (dmabuf vs legacy IPC handles: the knob RCCL's cross-process buffer registration depends on,
+    never exercised with N > 1 ranks on this pool) is a DEFAULT in bench.py, not a force: an operator's own value -- and
+    GPU_MAX_HW_QUEUES likewise -- must arrive in the ranks bench.py launches itself (line 463 used to
+    overwrite it with "0").  Each rank prints the values it sees when it fails for want of a GPU."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=_env(OTHELLO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="1", GPU_MAX_HW_QUEUES="6"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "ranks' environment: HSA_ENABLE_IPC_MODE_LEGACY=1 GPU_MAX_HW_QUEUES=6" in r.stderr       # the parent, before the launch
+    for rank in (0, 1):                                                                              # ... and every rank
+        line = [ln for ln in r.stderr.splitlines() if "rank %d/2" % rank in ln and "no gfx950" in ln]
+        assert line and "[HSA_ENABLE_IPC_MODE_LEGACY=1 GPU_MAX_HW_QUEUES=6]" in line[0], r.stderr[-2000:]
+    # unset by the caller: the defaults (dmabuf IPC, 8 hardware queues) arrive instead
+    env = _env(OTHELLO_DIST_BACKEND="gloo")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert "[HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=8]" in r.stderr, r.stderr[-2000:]
+
+
 def test_launcher_sigterm_ends_the_whole_stage_tree(tmp_path):
     """tests/gpu_children.py (the launcher of the GPU session's child stages) on SIGTERM: the running stage and everything
     under it -- here a grandchild in its OWN session, as bench.py's self-launched ranks are -- is gone, and the stage's rc

@@ -766,6 +766,123 @@ def test_rescue_replays_the_call_from_its_start_state(pkg):
                                           for p, q in zip(d1, d2))
 
 
+def test_weight_update_resets_the_activation_scale(pkg):
+    """The activation scale is a function of the WEIGHTS, not of the process's history (it used to be sticky -- one
+    saturating checkpoint lowered it, or switched the evaluator to fp32, for good).  When the trainer has stepped (the version
+    counters moved), refresh() goes back to scale 16 and the constructor's precision, uploads, and one launch over 256 fixed
+    probe positions lets the rescue lower the scale again if the NEW weights need it."""
+    import warnings
+    x = (torch.rand(64, 3, 8, 8, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    tame = _trained_like(pkg, 2, 64, 8)
+    amax1, _ = _max_activation(tame.cuda(), x)
+    tame.cpu()
+    wild = _trained_like(pkg, 2, 64, 8, boost=6000.0 / amax1)
+    model = pkg.OthelloResNet(2, 64).eval()
+    model.load_state_dict(wild.state_dict())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, model, num_simulations=4, num_parallel_games=8, verbose=False)
+        ev = w.batch_mcts.evaluator
+        np.random.seed(11)
+        w.execute_episodes(6)
+        low = ev.act_scale
+        assert low < 16.0 and len(ev.rescues) >= 1 and w.last_stats["act_scale"] == low and w.last_stats["rescues"] == len(ev.rescues)
+        # the trainer steps to tame weights: the scale goes back up, nothing is rescued
+        with torch.no_grad():
+            for p_, q_ in zip(list(model.parameters()) + list(model.buffers()), list(tame.parameters()) + list(tame.buffers())):
+                p_.copy_(q_)
+        k = len(ev.rescues)
+        np.random.seed(11)
+        d_tame = w.execute_episodes(6)
+        assert ev.act_scale == 16.0 and ev.precision == "f16x3" and len(ev.rescues) == k
+        # ... identical to a worker that never saw the wild weights
+        np.random.seed(11)
+        w2 = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, tame, num_simulations=4, num_parallel_games=8, verbose=False)
+        d_ref = w2.execute_episodes(6)
+        assert len(d_tame) == len(d_ref) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+                                                 for a, b in zip(d_tame, d_ref))
+        # ... and back to the wild ones: the probe launch of refresh() settles the scale BEFORE the call (no replayed call)
+        with torch.no_grad():
+            for p_, q_ in zip(list(model.parameters()) + list(model.buffers()), list(wild.parameters()) + list(wild.buffers())):
+                p_.copy_(q_)
+        ev.refresh()
+        assert ev.act_scale < 16.0 and len(ev.rescues) > k
+        # a forced re-upload of unchanged weights keeps the scale (no version change)
+        s_now = ev.act_scale
+        ev.refresh(force=True)
+        assert ev.act_scale == s_now
+
+
+def test_rescue_replay_with_the_evaluation_cache(pkg):
+    """The rescue's snapshot / restore with the evaluation cache ON (restore also clears the cache, resets its
+    epoch and puts back the cres / cstat rows, and that path was never replay-tested).  A stream whose evaluator is rescued at
+    its start and again in mid-stream (scale put back to 16 by hand, games in flight) returns the tuples, the counters AND the
+    cache statistics of a stream that had the final scale from the start; the lock-step search likewise (a replayed search
+    starts from an empty cache -- the abandoned call's entries may hold clamped rows -- so the reference search is started from
+    an empty cache too, by the same snapshot / restore pair)."""
+    import warnings
+    x = (torch.rand(64, 3, 8, 8, generator=torch.Generator().manual_seed(2)) < 0.35).float().cuda()
+    plain = _trained_like(pkg, 2, 64, 8)
+    amax1, _ = _max_activation(plain.cuda(), x)
+    net = _trained_like(pkg, 2, 64, 8, boost=6000.0 / amax1)
+
+    def set_scale(ev, s_):
+        pkg._lib.call("oth_net_set_act_scale", ev.handle, C.c_float(s_))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev0 = pkg.HipResNetEvaluator(net)
+        e0 = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev0)
+        e0.selfplay_run_rescued(24, seed=5)
+        final = ev0.act_scale
+        assert final < 16.0
+        # ---- streaming, cache of 2^12 entries
+        steps = (10, 7, 9, 5)
+        ev_ref = pkg.HipResNetEvaluator(net)
+        set_scale(ev_ref, final)
+        ref = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev_ref, eval_cache_log2=12)
+        ref.stream_begin(77, stagger_rounds=5)
+        want = _run_stream_steps(ref, steps, rescued=False)
+        assert ev_ref.rescues == [] and ref.counters()["cache_hits"] > 0
+        ev2 = pkg.HipResNetEvaluator(net)
+        e2 = pkg.SearchEngine(16, 6, temperature_threshold=8, evaluator=ev2, eval_cache_log2=12)
+        e2.stream_begin(77, stagger_rounds=5)
+        got = _run_stream_steps(e2, steps[:2], rescued=True)
+        assert ev2.act_scale == final and len(ev2.rescues) >= 1
+        set_scale(ev2, 16.0)
+        k = len(ev2.rescues)
+        got += _run_stream_steps(e2, steps[2:], rescued=True)
+        assert ev2.act_scale == final and len(ev2.rescues) > k
+        for w_, g_ in zip(want, got):
+            assert all(np.array_equal(p, q) for p, q in zip(w_, g_))
+        assert e2.counters() == ref.counters() and e2.cache_stats() == ref.cache_stats()
+        # ---- lock-step (the numpy-RNG worker's path), cache on: search, apply, search again with a rescue in between
+        ev3 = pkg.HipResNetEvaluator(net)
+        e3 = pkg.SearchEngine(4, 6, evaluator=ev3, eval_cache_log2=10)
+        e3.selfplay_begin(4)
+        pi1, act1 = e3.selfplay_search_rescued()
+        s3 = ev3.act_scale
+        ev_r3 = pkg.HipResNetEvaluator(net)
+        set_scale(ev_r3, s3)
+        r3 = pkg.SearchEngine(4, 6, evaluator=ev_r3, eval_cache_log2=10)
+        r3.selfplay_begin(4)
+        pr1, ar1 = r3.selfplay_search()
+        assert np.array_equal(pi1, pr1) and np.array_equal(act1, ar1) and e3.cache_stats() == r3.cache_stats()
+        actions = pi1.argmax(1).astype(np.int32)
+        e3.selfplay_apply(actions)
+        r3.selfplay_apply(actions)
+        set_scale(ev3, 16.0)
+        k = len(ev3.rescues)
+        pi2, _ = e3.selfplay_search_rescued()
+        assert len(ev3.rescues) > k
+        set_scale(ev_r3, ev3.act_scale)
+        r3.snapshot()
+        r3.restore()                                     # the replay's start state: this search's roots, an empty cache
+        pr2, _ = r3.selfplay_search()
+        assert np.array_equal(pi2, pr2) and not ev_r3.saturated()
+        assert e3.counters() == r3.counters() and e3.cache_stats() == r3.cache_stats()
+
+
 def test_bench_workload_rescues_across_lanes(pkg):
     """bench.py's own step (Workload.play): two lanes on two streams and host threads share ONE evaluator, every lane
     snapshots its stream before the step, and the rescue of a saturated launch is decided where both lanes have joined --
@@ -838,6 +955,55 @@ def test_lane_streams_are_made_once(pkg):
     d2 = w.execute_episodes(12)                      # second call: the same two streams, the same tuples
     assert len(d1) == len(d2) > 0 and all(np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(d1, d2))
     assert lane_streams(2)[0] is a[0]
+
+
+def test_lane_overlap_is_a_checked_property(pkg):
+    """Two lanes whose streams share a hardware queue serialise (round 5: -8...-10 %), and nothing used to notice.  bench.py's
+    Workload (and the multi-lane worker) now MEASURE the overlap on the first warm-up step -- sum of the trunk launch durations
+    / union of their intervals, from the HIP-event spans: the normal two-lane run reports >= 1.5; with both lanes bound to ONE
+    stream the detector flags it (< 1.2, RuntimeWarning, `lanes_serialised`), draws the streams once more from a widened pool
+    and the next step overlaps again.  (10x128 network, 2 x 1024 slots: launches of ~1 ms, long enough for the ratio to mean
+    something; toy networks are launch-bound and are never flagged.)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    E = pkg.engine
+    w = bench.Workload(pkg, torch, 8, 10, 128, 10, 2048, 2, 8, 64)
+    w.play(64, check=True)
+    rep = w.check.report()
+    print("\n    two lanes on their own streams: overlap %.2f (mean launch %.2f ms)" % (rep["lanes_overlap"], rep["mean_launch_ms"]))
+    assert rep["lanes_overlap"] >= 1.5 and rep["lanes_serialised"] is False and rep["stream_redraws"] == 0
+    assert not w.check.pending and not any(e.timing for e in w.engs)       # decided once; the hooks are off again
+    t0 = [tuple(t_.clone() for t_ in lane) for lane in w.play(64)[1]]      # (an unchecked step: no hooks)
+    # ---- both lanes on ONE stream, no redraw allowed: flagged
+    torch.cuda.synchronize()
+    one = w.streams[0]
+    w.streams = [one, one]
+    w.check = E.LaneOverlapCheck(2, w.dev, max_redraws=0)
+    E._WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="do not overlap"):
+        w.play(64, check=True)
+    rep = w.check.report()
+    print("    both lanes on one stream:        overlap %.2f" % rep["lanes_overlap"])
+    assert rep["lanes_overlap"] < 1.2 and rep["lanes_serialised"] is True and not w.check.pending
+    # ---- the same, one redraw allowed: the streams are drawn again and the NEXT step is measured on the new arrangement
+    torch.cuda.synchronize()
+    w.streams = [one, one]
+    w.check = E.LaneOverlapCheck(2, w.dev, max_redraws=1)
+    E._WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="do not overlap"):
+        w.play(64, check=True)
+    assert w.check.pending and w.streams[0] is not w.streams[1] and one not in w.streams
+    w.play(64, check=True)
+    rep = w.check.report()
+    print("    after the redraw:                overlap %.2f (arrangements tried: %s)" % (rep["lanes_overlap"], rep["arrangements_tried"]))
+    assert rep["stream_redraws"] == 1 and len(rep["arrangements_tried"]) == 2 and rep["arrangements_tried"][0] < 1.2
+    assert rep["lanes_overlap"] >= 1.5 and rep["lanes_serialised"] is False and not w.check.pending
+    assert len(t0) == 2                                                    # (tuples do not depend on the streams: exact tests)
+    w.close()
 
 
 def test_trunk_on_trained_like_weights(pkg):

@@ -27,27 +27,29 @@ def dev_u64(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=U64).view(np.int64)).cuda()
 
 
-def hip_net_eval(ev, cap):
+def hip_net_eval(ev, cap, olib=None):
     """orc_eval_fn whose answers are the HIP network's: oth_net_forward_bits on launches of `cap` rows (the shape
-    the engine launches, so the same kernel build runs) and oth_policy_exp (the engine's expf) for the priors."""
+    the engine launches, so the same kernel build runs) and oth_policy_exp (the engine's expf) for the priors.
+    olib: the oracle binding the callback is for (oracle_lib, or oracle_lib6 for a 6x6 network)."""
+    olib = olib or ol
     calls = {"n": 0, "pos": 0}
 
     def fn(s, o):
         n = len(s)
-        probs = np.empty((n, 65), dtype=np.float32)
+        probs = np.empty((n, olib.NPOL), dtype=np.float32)
         vals = np.empty(n, dtype=np.float32)
         for i in range(0, n, cap):
             m = min(cap, n - i)
             ss, oo = np.zeros(cap, dtype=U64), np.zeros(cap, dtype=U64)
             ss[:m], oo[:m] = s[i:i + m], o[i:i + m]
-            lg = ol.legal_batch(ss, oo)
+            lg = olib.legal_batch(ss, oo)
             logp, v = ev.forward_bits(dev_u64(ss), dev_u64(oo), dev_u64(lg))
             probs[i:i + m] = ev.policy_probs(logp)[:m].cpu().numpy()
             vals[i:i + m] = v[:m, 0].cpu().numpy()
         calls["n"] += 1
         calls["pos"] += n
         return probs, vals
-    cb = ol.make_eval(fn)
+    cb = olib.make_eval(fn)
     cb.calls = calls
     return cb
 
@@ -100,29 +102,49 @@ def test_selfplay_device_rng_exact(pkg, blocks, filters, sims, thr, slots, games
     assert c["evals"] == cb.calls["pos"]          # the engine evaluated exactly the positions the oracle asked for
 
 
-def test_selfplay_lanes_exact(pkg):
-    """ParallelSelfPlayWorker with two lanes (two engines, two streams, two host threads): each lane's share is an
-    independent run with its own seed; the concatenation equals the oracle's."""
-    torch.manual_seed(7)
-    net = pkg.OthelloResNet(2, 16).eval()
+@pytest.mark.parametrize("lanes,board,blocks,filters", [
+    pytest.param(2, 8, 2, 16, id="2-lanes-8x8-2x16"),
+    # lane counts > 2 are the shapes bench.py's secondary legs run at (configs[3]: three lanes, configs[4]: four): exact in every
+    # driver run, not only consistent
+    pytest.param(3, 8, 2, 32, id="3-lanes-8x8-2x32"),
+    pytest.param(4, 8, 2, 16, id="4-lanes-8x8-2x16"),
+    pytest.param(3, 6, 2, 32, id="3-lanes-6x6-2x32-rules-unpinned"),
+    pytest.param(4, 6, 2, 32, id="4-lanes-6x6-2x32-rules-unpinned"),
+])
+def test_selfplay_lanes_exact(pkg, lanes, board, blocks, filters):
+    """ParallelSelfPlayWorker with several lanes (one engine, stream and host thread per lane): each lane's share is an
+    independent run with its own seed; the concatenation equals the oracle's, lane by lane.  6x6: against the 6x6 twin of the
+    oracle (the reference has no 6x6 rules: parity unpinned)."""
+    if board == 6:
+        import oracle_lib6 as olib
+    else:
+        olib = ol
+    torch.manual_seed(7 + lanes)
+    net = pkg.OthelloResNet(blocks, filters, board_size=board).eval()
+    per = 16
     w = pkg.ParallelSelfPlayWorker(pkg.OthelloBitboard, net, num_simulations=6, temperature_threshold=8,
-                                   num_parallel_games=32, verbose=False, lanes=2)
+                                   num_parallel_games=per * lanes, verbose=False, lanes=lanes)
+    games = 25 * lanes + 1                   # (uneven shares: the first lane plays one game more)
     np.random.seed(21)
-    data = w.execute_episodes(50)
+    data = w.execute_episodes(games)
     np.random.seed(21)
     seed = int(np.random.randint(0, 2**62))
     ev = w.batch_mcts.evaluator
-    cb = hip_net_eval(ev, 16)
+    cb = hip_net_eval(ev, per, olib)
+    shares = [games // lanes + (1 if k < games % lanes else 0) for k in range(lanes)]
+    assert w._ran is w._lane_engines and [e.max_games for e in w._lane_engines] == [per] * lanes
     off = 0
-    for k, share in enumerate((25, 25)):
-        ws, wp, wz, wm, wl = ol.selfplay_philox(share, seed + 7919 * (k + 1), 6, 8, cb, parallel_games=16)
+    for k, share in enumerate(shares):
+        ws, wp, wz, wm, wl = olib.selfplay_philox(share, seed + 7919 * (k + 1), 6, 8, cb, parallel_games=per)
         n = len(wz)
         chunk = data[off:off + n]
-        assert np.array_equal(np.stack([d[0] for d in chunk]), ws)
-        assert np.array_equal(np.stack([d[1] for d in chunk]), wp)
-        assert np.array_equal(np.array([d[2] for d in chunk], dtype=np.float32), wz)
+        assert np.array_equal(np.stack([d[0] for d in chunk]), ws), "lane %d of %d: states" % (k, lanes)
+        assert np.array_equal(np.stack([d[1] for d in chunk]), wp), "lane %d of %d: pi" % (k, lanes)
+        assert np.array_equal(np.array([d[2] for d in chunk], dtype=np.float32), wz), "lane %d of %d: z" % (k, lanes)
         off += n
     assert off == len(data)
+    # the lane check ran on this first multi-lane call (toy launches are launch-bound: measured, never flagged)
+    assert w.last_stats["lanes_overlap"] is not None and w.last_stats["lanes_serialised"] is False
 
 
 def simulate_stream(lengths, slots, stagger, targets):
@@ -333,3 +355,44 @@ def test_worker_continuous_mode_exact_with_cache_and_refresh(pkg):
             off += b - a
         assert off == len(data)
     assert w.last_stats["cache_hits"] > 0
+
+
+def test_continuous_mode_from_the_yaml_key(pkg):
+    """`self_play.continuous: true` in the config dict create_parallel_self_play_worker takes (main.py:111-132 passes the YAML
+    through; the key is this package's, absent = the reference's call-by-call worker): what a trainer that asks for 100
+    episodes per iteration (configs/fast_8x8.yaml) gets -- two successive execute_episodes(100) calls return >= 100 games
+    each from slots that stay full, every game the oracle's game of the same id, tuple for tuple."""
+    torch.manual_seed(9)
+    net = pkg.OthelloResNet(2, 16).eval()
+    config = {"mcts": {"num_simulations": 6, "c_puct": 1.0, "dirichlet_alpha": 0.3, "dirichlet_epsilon": 0.25},
+              "self_play": {"temperature_threshold": 8, "num_parallel_games": 16, "continuous": True, "stagger_rounds": 16,
+                            "device_slots": 64}}
+    w = pkg.create_parallel_self_play_worker(config, net, verbose=False)
+    assert w.continuous and w.engine.max_games == 64 and w.stagger_rounds == 16
+    # absent key = the reference's behaviour
+    ref_cfg = {"mcts": config["mcts"], "self_play": {"temperature_threshold": 8, "num_parallel_games": 16}}
+    assert not pkg.create_parallel_self_play_worker(ref_cfg, net, verbose=False).continuous
+    np.random.seed(6)
+    calls, ids = [], []
+    for _ in range(2):
+        data = w.execute_episodes(100)
+        ids.append(w.last_game_ids.copy())
+        calls.append(data)
+        assert len(ids[-1]) >= 100 and w.last_stats["games"] == len(ids[-1])
+    all_ids = np.concatenate(ids)
+    assert len(set(all_ids.tolist())) == len(all_ids)
+    n_oracle = int(all_ids.max()) + 1
+    cb = hip_net_eval(w.batch_mcts.evaluator, 64)
+    ws, wp, wz, wm, wl = ol.selfplay_philox(n_oracle, w.stream_seed, 6, 8, cb, parallel_games=n_oracle)
+    woff = np.concatenate([[0], np.cumsum(wl)])
+    for data, gids in zip(calls, ids):
+        off = 0
+        for gid in gids:
+            a, b = woff[gid], woff[gid + 1]
+            chunk = data[off:off + (b - a)]
+            assert np.array_equal(np.stack([d[0] for d in chunk]), ws[a:b])
+            assert np.array_equal(np.stack([d[1] for d in chunk]), wp[a:b])
+            assert np.array_equal(np.array([d[2] for d in chunk], dtype=np.float32), wz[a:b])
+            off += b - a
+        assert off == len(data)
+    assert w.last_stats["act_scale"] is not None and w.last_stats["rescues"] == 0

@@ -39,5 +39,5 @@ for var in sys.argv[2:]:
     kw["step_games"] -= kw["step_games"] % kw["lanes"]
     r = bench.run_leg(pkg, torch, **kw)
     keep = ("value", "roofline_frac", "positions_per_launch", "net_time_share", "tree_kernels_ms", "avg_launch_ms", "leg_seconds",
-            "evals_per_game", "games_timed", "seconds_timed", "eval_cache")
+            "evals_per_game", "games_timed", "seconds_timed", "eval_cache", "lanes_overlap", "lanes_serialised")
     print(var, json.dumps({k: r[k] for k in keep if k in r}), flush=True)
