@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
         }
     }
 
+    // [layer loop: begin]  (tools/probes/apply_ablation.py w6_exp_lgpipe swaps everything up to "[layer loop: end]" for the
+    //                       lane-group pipeline of tools/probes/w6_lgpipe_loop.inc; comments only, the ISA is unchanged)
     const int n_layers = 1 + a.n_res_layers;
     uint32_t sat_bits = 0;
     OTH_W6STAMP(0)
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
         conv_d(std::integral_constant<int, 1>{});
         conv_d(std::integral_constant<int, 2>{});
     }
+    // [layer loop: end]
 
     // ---------------- heads (fp32 VALU): final activations (in `res`, x act_scale) -> LDS planes [channel][8 x 36 cells] f32
     //                  (aliasing V: every read of it is done), then each wave runs the shared one-wave head code on two

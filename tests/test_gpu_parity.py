@@ -962,8 +962,9 @@ def test_lane_overlap_is_a_checked_property(pkg):
     Workload (and the multi-lane worker) now MEASURE the overlap on the first warm-up step -- sum of the trunk launch durations
     / union of their intervals, from the HIP-event spans: the normal two-lane run reports >= 1.5; with both lanes bound to ONE
     stream the detector flags it (< 1.2, RuntimeWarning, `lanes_serialised`), draws the streams once more from a widened pool
-    and the next step overlaps again.  (10x128 network, 2 x 1024 slots: launches of ~1 ms, long enough for the ratio to mean
-    something; toy networks are launch-bound and are never flagged.)"""
+    and the next step overlaps again.  (10x128 network, 2 x 2048 slots as the headline: launches of ~2 ms -- measured 1.83 on
+    separate queues; at 2 x 1024 slots the figures were 1.51 / 1.18 / 1.67, too close to the bars; toy networks are launch-bound
+    and are never flagged.)"""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -971,7 +972,7 @@ def test_lane_overlap_is_a_checked_property(pkg):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     E = pkg.engine
-    w = bench.Workload(pkg, torch, 8, 10, 128, 10, 2048, 2, 8, 64)
+    w = bench.Workload(pkg, torch, 8, 10, 128, 10, 4096, 2, 8, 64)
     w.play(64, check=True)
     rep = w.check.report()
     print("\n    two lanes on their own streams: overlap %.2f (mean launch %.2f ms)" % (rep["lanes_overlap"], rep["mean_launch_ms"]))

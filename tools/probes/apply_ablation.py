@@ -104,6 +104,14 @@ ABLATIONS = {
         ("net_wino6.hip", "heads_wave_n<k6F, k6BS, 2, true>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);",
          "heads_wave_n<k6F, k6BS, 2, true>(a.heads, fc_lds, fc_lds + 2 * k6Cells * k6NP, srcs, NCO, scratch, lane, lps, vs, live);"),
     ]),
+    # ---- k_trunk_w6 experiment of round 6 (CORRECT results, bit-identical): VERDICT r5 item 3 -- the epilogue VALU of one lane group
+    #      in the MFMA gaps of another lane group's convolution.  The whole layer loop is swapped for tools/probes/w6_lgpipe_loop.inc
+    #      (its header explains why the unit is the lane group, not a half-group of four positions, and the schedule); build with
+    #      -DOTH_W6_VP=<VALU per MFMA gap asked of the scheduler> (default 2).
+    "w6_exp_lgpipe": ("lane-group pipeline: epilogue VALU interleaved with another lane group's MFMAs (correct results)", [
+        ("net_wino6.hip", ("REGION", "    // [layer loop: begin]", "    // [layer loop: end]\n"),
+         ("FILE", "w6_lgpipe_loop.inc")),
+    ]),
 }
 
 
@@ -112,6 +120,14 @@ def apply(name, srcdir):
     for fname, search, replace in edits:
         path = os.path.join(srcdir, fname)
         text = open(path).read()
+        if isinstance(search, tuple):   # ("REGION", begin marker, end marker): everything from the first to the end of the second
+            _, m0, m1 = search
+            if text.count(m0) != 1 or text.count(m1) != 1:
+                raise SystemExit("apply_ablation %s: region markers not found exactly once in %s" % (name, fname))
+            a, b = text.index(m0), text.index(m1) + len(m1)
+            search = text[a:b]
+        if isinstance(replace, tuple):  # ("FILE", name): the content of a file next to this script
+            replace = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), replace[1])).read()
         if text.count(search) != 1:
             raise SystemExit("apply_ablation %s: the text to replace occurs %d times in %s (the product source moved on: "
                              "update tools/probes/apply_ablation.py)" % (name, text.count(search), fname))
