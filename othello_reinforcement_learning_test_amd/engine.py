@@ -297,21 +297,24 @@ def union_ms(spans):
 # drops to ~2.  Launches shorter than MIN_LAUNCH_MS are launch-bound (toy networks): the host cannot keep two queues fed,
 # the ratio says nothing about the queues and nothing is flagged.
 OVERLAP_MIN_LAUNCH_MS = 0.25
+OVERLAP_MIN_LAUNCHES = 100      # per lane, before LaneOverlapCheck decides: a 2-ply-round step (22 launches per lane) is too noisy
 
 
 def overlap_floor(lanes):
     return 1.0 + 0.3 * (max(1, int(lanes)) - 1)
 
 
-def lanes_overlap(engines):
+def lanes_overlap(engines, carry=None):
     """-> dict(overlap, sum_ms, union_ms, launches, mean_launch_ms, lanes, serialised) from the HIP-event spans the engines
     recorded during their last run / step (SearchEngine.set_timing(True) before it).  overlap = sum of the network launch
     durations / union of their intervals on the process-wide time axis: ~1 when the lanes' launches alternate, -> the lane
-    count when every lane always has a launch running."""
+    count when every lane always has a launch running.  `carry`: an earlier result of the same arrangement to add this step to."""
     spans = [e.net_spans() for e in engines]
     tot = float(sum(float((s[:, 1] - s[:, 0]).sum()) for s in spans if len(s)))
     n = int(sum(len(s) for s in spans))
     uni = union_ms(spans)
+    if carry:
+        tot, uni, n = tot + carry["sum_ms"], uni + carry["union_ms"], n + carry["launches"]
     ov = tot / uni if uni > 0 else 0.0
     mean = tot / n if n else 0.0
     lanes = len(engines)
@@ -337,11 +340,15 @@ class LaneOverlapCheck:
     turns them off, computes ``lanes_overlap`` and decides: a serialised run is reported once on stderr (RuntimeWarning),
     and -- while redraws are left -- the lanes' streams are drawn once more from a widened pool (``lane_streams(redraw=
     True)``) so that the caller's NEXT run is measured on the new arrangement; the better of the arrangements seen is kept.
-    ``pending`` says whether the next run should be measured too.  ``report()`` -> what bench.py / last_stats print."""
+    ``pending`` says whether the next run should be measured too (also while fewer than ``min_launches`` launches per lane have
+    been seen on the current arrangement: the decision is taken on the accumulated sample).  ``report()`` -> what bench.py /
+    last_stats print."""
 
-    def __init__(self, lanes, device=None, max_redraws=1):
+    def __init__(self, lanes, device=None, max_redraws=1, min_launches=OVERLAP_MIN_LAUNCHES):
         self.lanes, self.device = int(lanes), device
         self.max_redraws = int(max_redraws)
+        self.min_launches = int(min_launches)
+        self._carry = None
         self.history = []            # [(pool start, lanes_overlap dict)]
         self.pending = self.lanes > 1
         self.redraws = 0
@@ -361,9 +368,13 @@ class LaneOverlapCheck:
 
     def end(self, engines):
         """-> True when the caller must fetch its streams again (lane_streams) before the next run."""
-        m = lanes_overlap(engines)
+        m = lanes_overlap(engines, self._carry)
         for e, was in zip(engines, self._was):
             e.set_timing(was)
+        if m["launches"] < self.min_launches * self.lanes and m["mean_launch_ms"] >= OVERLAP_MIN_LAUNCH_MS:
+            self._carry = m          # too small a sample to decide on: measure the next run as well
+            return False
+        self._carry = None
         start = lane_streams_start(self.device)
         self.history.append((start, m))
         self.pending = False
@@ -399,6 +410,8 @@ class LaneOverlapCheck:
 
     def report(self):
         if not self.history:
+            if self._carry:
+                return {"lanes_overlap": self._carry["overlap"], "lanes_serialised": False, "undecided_after_launches": self._carry["launches"]}
             return {"lanes_overlap": None, "lanes_serialised": None}
         kept = self.history[self.kept if self.kept is not None else -1][1]
         return {"lanes_overlap": kept["overlap"], "lanes_serialised": kept["serialised"], "floor": kept["floor"],

@@ -961,22 +961,34 @@ def test_lane_overlap_is_a_checked_property(pkg):
     """Two lanes whose streams share a hardware queue serialise (round 5: -8...-10 %), and nothing used to notice.  bench.py's
     Workload (and the multi-lane worker) now MEASURE the overlap on the first warm-up step -- sum of the trunk launch durations
     / union of their intervals, from the HIP-event spans: the normal two-lane run reports >= 1.5; with both lanes bound to ONE
-    stream the detector flags it (< 1.2, RuntimeWarning, `lanes_serialised`), draws the streams once more from a widened pool
+    stream the detector flags it (below the floor of 1.3: RuntimeWarning, `lanes_serialised`), draws the streams once more from a widened pool
     and the next step overlaps again.  (10x128 network, 2 x 2048 slots as the headline: launches of ~2 ms -- measured 1.83 on
     separate queues; at 2 x 1024 slots the figures were 1.51 / 1.18 / 1.67, too close to the bars; toy networks are launch-bound
     and are never flagged.)"""
     import importlib.util
     import os
+    import warnings
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     E = pkg.engine
+
+    def decide(w_):
+        """steps with the check on until it has decided on the current arrangement (>= 100 launches per lane seen)"""
+        k, n = len(w_.check.history), 0
+        while len(w_.check.history) == k:
+            w_.play(64, check=True)
+            n += 1
+            assert n < 80
+        return w_.check.history[-1][1]
+
     w = bench.Workload(pkg, torch, 8, 10, 128, 10, 4096, 2, 8, 64)
-    w.play(64, check=True)
+    m = decide(w)
     rep = w.check.report()
-    print("\n    two lanes on their own streams: overlap %.2f (mean launch %.2f ms)" % (rep["lanes_overlap"], rep["mean_launch_ms"]))
+    print("\n    two lanes on their own streams: overlap %.2f (%d launches, mean %.2f ms)" % (m["overlap"], m["launches"], m["mean_launch_ms"]))
     assert rep["lanes_overlap"] >= 1.5 and rep["lanes_serialised"] is False and rep["stream_redraws"] == 0
+    assert m["launches"] >= 2 * E.OVERLAP_MIN_LAUNCHES
     assert not w.check.pending and not any(e.timing for e in w.engs)       # decided once; the hooks are off again
     t0 = [tuple(t_.clone() for t_ in lane) for lane in w.play(64)[1]]      # (an unchecked step: no hooks)
     # ---- both lanes on ONE stream, no redraw allowed: flagged
@@ -985,23 +997,29 @@ def test_lane_overlap_is_a_checked_property(pkg):
     w.streams = [one, one]
     w.check = E.LaneOverlapCheck(2, w.dev, max_redraws=0)
     E._WARNED.clear()
-    with pytest.warns(RuntimeWarning, match="do not overlap"):
-        w.play(64, check=True)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        m = decide(w)
     rep = w.check.report()
-    print("    both lanes on one stream:        overlap %.2f" % rep["lanes_overlap"])
-    assert rep["lanes_overlap"] < 1.2 and rep["lanes_serialised"] is True and not w.check.pending
-    # ---- the same, one redraw allowed: the streams are drawn again and the NEXT step is measured on the new arrangement
+    print("    both lanes on one stream:        overlap %.2f (%d launches, mean %.2f ms)" % (m["overlap"], m["launches"], m["mean_launch_ms"]))
+    # (two lanes on ONE stream measure 1.13-1.20, not 1.0: the HIP-event intervals of consecutive launches of a stream overlap a
+    # little; two streams on one hardware queue measure 1.00-1.02, profiles/r06_lane_redraw_ab*.log; the floor for two lanes is 1.3)
+    assert rep["lanes_overlap"] < E.overlap_floor(2) and rep["lanes_serialised"] is True and not w.check.pending
+    assert any("do not overlap" in str(x.message) for x in wl)
+    # ---- the same, one redraw allowed: the streams are drawn again and the NEXT steps are measured on the new arrangement
     torch.cuda.synchronize()
     w.streams = [one, one]
     w.check = E.LaneOverlapCheck(2, w.dev, max_redraws=1)
     E._WARNED.clear()
-    with pytest.warns(RuntimeWarning, match="do not overlap"):
-        w.play(64, check=True)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        decide(w)
+    assert any("do not overlap" in str(x.message) for x in wl), w.check.history
     assert w.check.pending and w.streams[0] is not w.streams[1] and one not in w.streams
-    w.play(64, check=True)
+    decide(w)
     rep = w.check.report()
     print("    after the redraw:                overlap %.2f (arrangements tried: %s)" % (rep["lanes_overlap"], rep["arrangements_tried"]))
-    assert rep["stream_redraws"] == 1 and len(rep["arrangements_tried"]) == 2 and rep["arrangements_tried"][0] < 1.2
+    assert rep["stream_redraws"] == 1 and len(rep["arrangements_tried"]) == 2 and rep["arrangements_tried"][0] < E.overlap_floor(2)
     assert rep["lanes_overlap"] >= 1.5 and rep["lanes_serialised"] is False and not w.check.pending
     assert len(t0) == 2                                                    # (tuples do not depend on the streams: exact tests)
     w.close()

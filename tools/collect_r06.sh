@@ -2,7 +2,7 @@
 # Round-6 evidence run on the GPU box (repo root): everything lands in gpurun_out/r06/ as small text files; the files that back a
 # DESIGN claim are copied to profiles/r06_* afterwards (profiles/README.md is the index).
 # usage: bash tools/collect_r06.sh [part ...]   (default: tests nets)
-#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw w6
+#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw small w6
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
@@ -47,4 +47,6 @@ overlap)  # item 1b: the detector's own GPU test, verbose
   python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -s -k "lane_overlap or lane_streams" > $O/lane_overlap.log 2>&1; rc=$?; tail -8 $O/lane_overlap.log; [ $rc -eq 0 ] || exit $rc ;;
 redraw)   # item 1b: does drawing the streams again repair a serialised arrangement?  (same-box A/B)
   timeout -k 10 500 python3 tools/lane_redraw_ab.py > $O/lane_redraw_ab.log 2>&1; rc=$?; cat $O/lane_redraw_ab.log | cut -c1-220; [ $rc -eq 0 ] || exit $rc ;;
+small)    # item 5: the drop-in at the reference's own call sizes, batch and continuous mode (INTEGRATION.md section 1's table)
+  timeout -k 10 400 python3 tools/small_config_rate.py 2>&1 | grep -v amdgpu > $O/small_config.log; rc=$?; cat $O/small_config.log; [ $rc -eq 0 ] || exit $rc ;;
 esac; done
