@@ -2,7 +2,7 @@
 # Round-6 evidence run on the GPU box (repo root): everything lands in gpurun_out/r06/ as small text files; the files that back a
 # DESIGN claim are copied to profiles/r06_* afterwards (profiles/README.md is the index).
 # usage: bash tools/collect_r06.sh [part ...]   (default: tests nets)
-#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw small w6
+#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw small w6 w6pmc
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
@@ -47,6 +47,11 @@ overlap)  # item 1b: the detector's own GPU test, verbose
   python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -s -k "lane_overlap or lane_streams" > $O/lane_overlap.log 2>&1; rc=$?; tail -8 $O/lane_overlap.log; [ $rc -eq 0 ] || exit $rc ;;
 redraw)   # item 1b: does drawing the streams again repair a serialised arrangement?  (same-box A/B)
   timeout -k 10 500 python3 tools/lane_redraw_ab.py > $O/lane_redraw_ab.log 2>&1; rc=$?; cat $O/lane_redraw_ab.log | cut -c1-220; [ $rc -eq 0 ] || exit $rc ;;
+w6)       # item 3: the lane-group pipeline of k_trunk_w6 against the product (builds: see tools/probes/r06_w6_lgpipe.sh) + its PMC passes
+  bash tools/probes/r06_w6_lgpipe.sh > /dev/null || exit 1; tail -12 $O/w6_lgpipe.log | cut -c1-200
+  OTHELLO_MI355X_LIB=build/w6_lgpipe2/libothello_mi355x.so tools/pmc_netbench.sh 5x64x6:f16x3 w6lg > $O/w6_lgpipe_pmc.txt 2>&1; tail -4 $O/w6_lgpipe_pmc.txt | cut -c1-200 ;;
+w6pmc)    # only the PMC passes of the pipeline build
+  OTHELLO_MI355X_LIB=build/w6_lgpipe2/libothello_mi355x.so tools/pmc_netbench.sh 5x64x6:f16x3 w6lg > $O/w6_lgpipe_pmc.txt 2>&1; tail -4 $O/w6_lgpipe_pmc.txt | cut -c1-200 ;;
 small)    # item 5: the drop-in at the reference's own call sizes, batch and continuous mode (INTEGRATION.md section 1's table)
   timeout -k 10 400 python3 tools/small_config_rate.py 2>&1 | grep -v amdgpu > $O/small_config.log; rc=$?; cat $O/small_config.log; [ $rc -eq 0 ] || exit $rc ;;
 esac; done

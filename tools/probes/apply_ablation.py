@@ -107,7 +107,8 @@ ABLATIONS = {
     # ---- k_trunk_w6 experiment of round 6 (CORRECT results, bit-identical): VERDICT r5 item 3 -- the epilogue VALU of one lane group
     #      in the MFMA gaps of another lane group's convolution.  The whole layer loop is swapped for tools/probes/w6_lgpipe_loop.inc
     #      (its header explains why the unit is the lane group, not a half-group of four positions, and the schedule); build with
-    #      -DOTH_W6_VP=<VALU per MFMA gap asked of the scheduler> (default 2).
+    #      `-mllvm -pragma-unroll-threshold=4000000` (the 96-step loops with the micro-op chain are past hipcc's default limit for a
+    #      `#pragma unroll`), optionally -DOTH_W6_RING=3.  Measured and closed: DESIGN.md section 7, profiles/r06_w6_lgpipe_*.log.
     "w6_exp_lgpipe": ("lane-group pipeline: epilogue VALU interleaved with another lane group's MFMAs (correct results)", [
         ("net_wino6.hip", ("REGION", "    // [layer loop: begin]", "    // [layer loop: end]\n"),
          ("FILE", "w6_lgpipe_loop.inc")),
