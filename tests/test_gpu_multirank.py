@@ -45,6 +45,15 @@ def _check_small_bench(d, w, err):
     assert d["ranks"] == w and len(d["per_rank_games_per_s"]) == w and all(r > 0 for r in d["per_rank_games_per_s"])
     assert abs(sum(d["per_rank_games_per_s"]) - d["value"]) < 0.25 * d["value"]   # (each rank's own clock vs the slowest's)
     assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
+    # round 6: every rank's lane overlap and mean launch duration (a slow rank is attributable to serialisation vs clock), and
+    # the runtime knobs the ranks ran under
+    assert len(d["per_rank_lanes_overlap"]) == w and len(d["per_rank_avg_launch_ms"]) == w
+    assert all(o > 0 for o in d["per_rank_lanes_overlap"]) and all(m > 0 for m in d["per_rank_avg_launch_ms"])
+    env = d["runtime_env"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["GPU_MAX_HW_QUEUES"] and env["package_imported_before_hip_runtime"] is True
+    r = d["roofline"]
+    assert r["lanes_overlap"] > 0 and r["lanes_serialised"] is False      # (toy launches are launch-bound: measured, never flagged)
+    assert "lanes_overlap" in r["lanes_check_warmup"]
 
 
 def test_bench_multi_rank_rehearsal(children):
@@ -99,6 +108,7 @@ def test_bench_other_configs_leg_small():
     a = bench.run_leg(pkg, torch, "toy 6x6", "three lanes", board=6, blocks=2, filters=32, sims=4, games=96, step_games=48,
                       warmup=1, steps=2, lanes=3, stagger=8)
     assert a["value"] > 0 and a["games_timed"] >= 96 and a["kernel"].startswith("k_trunk_h3") and a["lanes"] == 3
+    assert a["lanes_overlap"] > 0 and a["lanes_serialised"] is False and "lanes_overlap" in a["lanes_check_warmup"]
     assert 0 < a["roofline_frac"] < 1 and a["mfma_flops_issued_per_algorithmic_flop"] >= 3.0 and a["plies_per_game"] > 20
     b = bench.run_leg(pkg, torch, "toy cache", "cache on", board=8, blocks=2, filters=16, sims=6, games=64, step_games=32,
                       warmup=1, steps=2, eval_cache=12, c_puct=1.5, temp_threshold=20, stagger=8)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side traffic of bench.py's OWN launches (two lanes, ~2 000 positions per trunk launch): separate rocprofv3 --pmc passes
-# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/r05_bench_traffic.json
+# (--kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short bench.py run; writes gpurun_out/${OTH_ROUND:-r06}_bench_traffic.json
 # (copy it to profiles/: bench.py reads roofline.traffic and roofline_rollout.traffic from there) and a text summary.
 set -e
 cd "$(dirname "$0")/.."
@@ -49,7 +49,7 @@ for kern, v in vals.items():
     }
     if wide:
         res["kernels"][key]["positions_per_launch"] = ppl
-json.dump(res, open("gpurun_out/r05_bench_traffic.json", "w"), indent=1)
+import os; json.dump(res, open("gpurun_out/%s_bench_traffic.json" % os.environ.get("OTH_ROUND", "r06"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf "$out"/fetch "$out"/write "$out"/tcc
