@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
                 for (int r = 0; r < 4; ++r) planes[(ch0 + r) * NCO + ci] = v[r] * us;
             }
     __syncthreads();
+    // [heads: begin]
     {
         float* scratch = (float*)(lds + (size_t)k6F * NCO * 4) + wave * 2 * 192;
         const int cc = lane < k6Cells ? lane : 0;
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(k6Regs))) void 
         }
         heads_wave_n<k6F, k6BS, 2, true>(a.heads, a.pfc_wt, a.vfc1_wt, srcs, NCO, scratch, lane, lps, vs, live);
     }
+    // [heads: end]
 #ifdef OTH_STAMPS
     OTH_W6STAMP(4)
     if (a.dbg && lane == 0) {

@@ -73,3 +73,79 @@ def test_hand_driven_search_matches_oracle(golden):
         _, n, w, _ = ol.search(root_board, 25, 1.0, 1.0, ev)
         for a, ch in root.children.items():
             assert ch.visit_count == n[a] and ch.value_sum == w[a]
+
+
+def test_lane_overlap_check_state_machine(monkeypatch):
+    """engine.LaneOverlapCheck without a GPU (fake engines with synthetic launch spans; the stream pool stubbed): it decides only
+    on >= min_launches per lane, flags a serialised arrangement once (RuntimeWarning), asks for a redraw and a re-measurement,
+    keeps the better arrangement, and leaves the engines' timing hooks as it found them.  Launch-bound spans (< 0.25 ms) are
+    measured but never flagged."""
+    import warnings
+
+    import numpy as np
+
+    import othello_reinforcement_learning_test_amd.engine as E
+
+    class Fake:
+        def __init__(self):
+            self.timing, self.sp = False, np.zeros((0, 2))
+
+        def set_timing(self, on):
+            self.timing = on
+
+        def net_spans(self):
+            return self.sp
+
+    state = {"start": 0, "redraws": 0, "selected": []}
+    monkeypatch.setattr(E, "lane_streams", lambda n, d=None, redraw=False: state.__setitem__("redraws", state["redraws"] + int(redraw)))
+    monkeypatch.setattr(E, "lane_streams_start", lambda d=None: state["redraws"])
+    monkeypatch.setattr(E, "lane_streams_select", lambda s, d=None: state["selected"].append(s))
+    E._WARNED.clear()
+
+    def spans(n, serial, ms=1.0):
+        a, b = Fake(), Fake()
+        t = np.arange(n) * 2.0 * ms
+        a.sp = np.stack([t, t + ms], 1)
+        off = ms if serial else 0.1 * ms
+        b.sp = np.stack([t + off, t + off + ms], 1)
+        return [a, b]
+
+    assert E.overlap_floor(1) == 1.0 and E.overlap_floor(2) == 1.3 and abs(E.overlap_floor(4) - 1.9) < 1e-9
+    assert E.union_ms([np.array([[0.0, 2.0], [5.0, 6.0]]), np.array([[1.0, 3.0]])]) == 4.0
+    c = E.LaneOverlapCheck(2, 0, max_redraws=1)
+    e = spans(30, True)
+    c.begin(e)
+    assert all(x.timing for x in e)
+    assert c.end(e) is False and c.pending and c.report()["undecided_after_launches"] == 60     # too small a sample
+    assert not any(x.timing for x in e)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        e = spans(90, True)
+        c.begin(e)
+        assert c.end(e) is True and c.pending and state["redraws"] == 1                          # flagged on 240 launches, redrawn
+        assert len([x for x in w if "do not overlap" in str(x.message)]) == 1
+    e = spans(120, False)
+    c.begin(e)
+    assert c.end(e) is False and not c.pending
+    r = c.report()
+    assert r["lanes_serialised"] is False and r["lanes_overlap"] > 1.7 and r["stream_redraws"] == 1 and r["arrangements_tried"][0] == 1.0
+    # a redraw that does NOT help: the better of the two arrangements is selected again
+    state.update(redraws=0, selected=[])
+    E._WARNED.clear()
+    c = E.LaneOverlapCheck(2, 0, max_redraws=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n_, ser in ((120, True), (120, True)):
+            e = spans(n_, ser)
+            c.begin(e)
+            c.end(e)
+    assert not c.pending and c.report()["lanes_serialised"] is True and c.report()["stream_redraws"] == 1
+    # launch-bound toy launches: measured, never flagged; hooks that were on stay on
+    c = E.LaneOverlapCheck(2, 0)
+    e = spans(400, True, ms=0.02)
+    for x in e:
+        x.timing = True
+    c.begin(e)
+    assert c.end(e) is False and not c.pending and c.report()["lanes_serialised"] is False and all(x.timing for x in e)
+    # one lane: nothing to check
+    assert E.LaneOverlapCheck(1, 0).pending is False

@@ -113,6 +113,11 @@ ABLATIONS = {
         ("net_wino6.hip", ("REGION", "    // [layer loop: begin]", "    // [layer loop: end]\n"),
          ("FILE", "w6_lgpipe_loop.inc")),
     ]),
+    # ---- k_trunk_w6 heads, cooperative form (round 6; CORRECT results, bit-identical): the value FC1 once per workgroup (thread =
+    #      output, all eight positions) and every FC weight requested up front -- tools/probes/w6_coop_heads.inc.
+    "w6_exp_coop_heads": ("cooperative heads of k_trunk_w6 (correct, bit-identical results)", [
+        ("net_wino6.hip", ("REGION", "    // [heads: begin]", "    // [heads: end]\n"), ("FILE", "w6_coop_heads.inc")),
+    ]),
 }
 
 
