@@ -27,6 +27,7 @@
 #include "common.h"
 #include "net.h"
 #include "othello_rules.h"
+#include "wave_bfly.h"
 
 namespace oth {
 
@@ -96,21 +97,10 @@ struct Dev {  // device pointers + scalars handed to every kernel by value
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
+// (xor butterflies without the LDS crossbar: wave_bfly.h; same pairing as the __shfl_xor loops they replaced, same results)
+__device__ __forceinline__ double wave_max_f64(double v) { return bfly_max_f64(v); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return bfly_sum_i32(v); }
+__device__ __forceinline__ int wave_max_i32(int v) { return bfly_max_i32(v); }
 
 // mcts.py:152-168 / parallel_self_play.py:199-204: child.update(v); v = -v from the leaf upwards.
 // Edges on a path are distinct, so lane i updates path entry i (sign by distance from the leaf).

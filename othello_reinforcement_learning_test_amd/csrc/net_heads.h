@@ -1,6 +1,7 @@
 // net_heads.h -- policy and value heads (fp32 VALU), shared by the generic and the MFMA trunk kernels.
 #pragma once
 #include "net.h"
+#include "wave_bfly.h"
 
 namespace oth {
 
@@ -52,15 +53,15 @@ __device__ inline void heads_forward(const HeadParams& hp, int F, const float* a
     __syncthreads();
     if (t < 64) {  // wave 0: log_softmax over 65 logits and the fc2 dot product
         float m = fmaxf(lg[t], t == 0 ? lg[64] : -INFINITY);
-        for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        m = bfly_max_f32(m);
         float s = expf(lg[t] - m) + (t == 0 ? expf(lg[64] - m) : 0.f);
-        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+        s = bfly_sum_f32(s);
         const float lse = logf(s);
         logp65[t] = lg[t] - m - lse;
         if (t == 0) logp65[64] = lg[64] - m - lse;
         float acc = 0.f;
         for (int i = t; i < 256; i += 64) acc = fmaf(hp.vfc2_w[i], h1[i], acc);
-        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+        acc = bfly_sum_f32(acc);
         if (t == 0) *v1 = tanhf(acc + hp.vfc2_b[0]);
     }
     __syncthreads();

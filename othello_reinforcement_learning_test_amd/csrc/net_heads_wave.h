@@ -2,19 +2,13 @@
 // shared by the wave-per-position trunk kernels (net_f32.hip, net_h3.hip).  Reference: net.py:62-136.
 #pragma once
 #include "net.h"
+#include "wave_bfly.h"
 
 namespace oth {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
+// xor-butterfly reductions over the wave: register-to-register (wave_bfly.h), bit-identical to the __shfl_xor loops they replaced
+__device__ __forceinline__ float wave_sum(float v) { return bfly_sum_f32(v); }
+__device__ __forceinline__ float wave_max(float v) { return bfly_max_f32(v); }
 
 // `src[p]` = address of channel 0 of THIS LANE's cell of position p (lane = cell index; lanes >= BS*BS pass any valid
 // cell), channel ch at src[p][ch * plane_stride]; scratch: 192 * P floats of LDS private to the wave; pfc_wt / vfc1_wt: FC

@@ -191,13 +191,13 @@ __device__ __forceinline__ void heads_block2(const HeadParams& hp, const float* 
         const float gl = gp[l] + gp[72 + l];
         const float g64 = gp[64] + gp[72 + 64];
         float m = fmaxf(gl, l == 0 ? g64 : -INFINITY);
-        for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        m = bfly_max_f32(m);
         float s = expf(gl - m) + (l == 0 ? expf(g64 - m) : 0.f);
-        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+        s = bfly_sum_f32(s);
         const float lse = logf(s);
         float acc = 0.f;
         for (int i = l; i < 256; i += 64) acc = fmaf(hp.vfc2_w[i], h1[p * 256 + i], acc);
-        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+        acc = bfly_sum_f32(acc);
         if (p == 0 || live1) {
             logp[p * 65 + l] = gl - m - lse;
             if (l == 0) {
