@@ -104,7 +104,7 @@ def planned_seconds(steps, warmup, step_games, slots=4096, stagger=61, profile_s
     return t + max(1.4 * cpu_budget, 45.0) + 10.0
 
 
-TRUNK_SOURCES = ("net_wino.hip", "net_epilogue.h", "net_heads.h", "net.h", "Makefile")
+TRUNK_SOURCES = ("net_wino.hip", "net_epilogue.h", "net_heads.h", "wave_bfly.h", "net.h", "Makefile")
 
 
 def trunk_source_sha256():

@@ -88,7 +88,8 @@ def test_committed_traffic_knows_when_it_is_stale(tmp_path, monkeypatch):
     # a file without a hash, or with another one, is stale
     prof = tmp_path / "profiles"
     prof.mkdir()
-    real = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_traffic.json")))
+    import glob
+    real = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_traffic.json")))[-1]))   # the newest
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
     csrc = tmp_path / "othello_reinforcement_learning_test_amd" / "csrc"
     csrc.mkdir(parents=True)
