@@ -2,7 +2,7 @@
 # Round-6 evidence run on the GPU box (repo root): everything lands in gpurun_out/r06/ as small text files; the files that back a
 # DESIGN claim are copied to profiles/r06_* afterwards (profiles/README.md is the index).
 # usage: bash tools/collect_r06.sh [part ...]   (default: tests nets)
-#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw small soak w6 w6pmc
+#   parts: smoke tests driver stats pmc nets cache exact exact3 exact4 rccl1 overlap redraw small soak longrun w6 w6pmc
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
@@ -55,6 +55,9 @@ w6pmc)    # only the PMC passes of the pipeline build
 soak)     # the wide parity sweep and the full-size exact run on the final build
   python3 tools/parity_sweep.py > $O/parity_sweep.log 2>&1; rc=$?; tail -1 $O/parity_sweep.log; [ $rc -eq 0 ] || exit $rc
   python3 tools/fullsize_exact.py > $O/fullsize_exact.log 2>&1; rc=$?; tail -1 $O/fullsize_exact.log; [ $rc -eq 0 ] || exit $rc ;;
+longrun)  # stability: 120 timed steps of the headline (~5.5 minutes of steady state), no legs, no CPU baseline
+  python3 bench.py --gpus 1 --steps 120 --warmup 5 --no-other-configs --no-cpu-baseline > $O/soak_120steps.json 2> $O/soak_120steps.stderr.txt || exit 1
+  python3 tools/print_bench_lines.py $O/soak_120steps.json ;;
 small)    # item 5: the drop-in at the reference's own call sizes, batch and continuous mode (INTEGRATION.md section 1's table)
   timeout -k 10 400 python3 tools/small_config_rate.py 2>&1 | grep -v amdgpu > $O/small_config.log; rc=$?; cat $O/small_config.log; [ $rc -eq 0 ] || exit $rc ;;
 esac; done
