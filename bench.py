@@ -564,6 +564,24 @@ def launch_ranks(n_ranks, argv):
     return rc if rc >= 0 else 128 - rc
 
 
+def first_contact_hint(stage, exc, rank=0, world=1):
+    """What an operator should flip first when the N > 1 path fails at its first contact with RCCL: the text
+    printed on stderr before the exception goes on.  No multi-GPU node was available to any round of this build, so the first
+    N > 1 run is also the first time the IPC mode below is exercised."""
+    return ("[bench rank %d/%d] %s failed: %r\n"
+            "  This path has never run with more than one RCCL rank (no multi-GPU node was available to the build).  In order:\n"
+            "  1. HSA_ENABLE_IPC_MODE_LEGACY is %s here (0 = dmabuf IPC handles, the only kind the build pool's host driver exports; the\n"
+            "     symptom of the wrong mode is `hipIpcGetMemHandle: invalid argument`): try the other value, e.g.\n"
+            "     HSA_ENABLE_IPC_MODE_LEGACY=%s python bench.py --gpus %d ...   (the self-launched ranks inherit it)\n"
+            "  2. NCCL_DEBUG=INFO shows the transport RCCL chose and where it stopped.\n"
+            "  3. OTHELLO_DIST_BACKEND=gloo runs the same control flow with the exchange on host copies (a line marked REHEARSAL): it\n"
+            "     separates a transport problem from a problem of this code.\n"
+            "  GPU_MAX_HW_QUEUES is %s (8 by default here; RCCL's own streams take hardware queues too: per_rank_lanes_overlap in the\n"
+            "  JSON line shows whether the lanes still overlap)."
+            % (rank, world, stage, exc, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+               "1" if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") == "0" else "0", world, os.environ.get("GPU_MAX_HW_QUEUES")))
+
+
 def check_world(args, argv):
     """The launch environment against --gpus, BEFORE torch / the package / the GPU: returns None to go on as one rank of
     the job, or the exit code of the self-launched job."""
@@ -648,7 +666,12 @@ def main():
     import othello_reinforcement_learning_test_amd as pkg
     from othello_reinforcement_learning_test_amd import distributed as D
 
-    rank, world, local = D.init_from_env()
+    try:
+        rank, world, local = D.init_from_env()
+    except Exception as exc:   # rendezvous / communicator creation: the first contact of an N > 1 job
+        print(first_contact_hint("torch.distributed initialisation", exc, int(os.environ.get("RANK", "0")), args.gpus),
+              file=sys.stderr, flush=True)
+        raise
     assert world == args.gpus, (world, args.gpus)   # (check_world above)
     try:
         pkg._lib.require_device()   # no GPU => fail loudly
@@ -736,10 +759,20 @@ def main():
     counters = wl.counters
     beat("setup done (%dx%d net, %d slots in %d lanes, %d sims); warm-up: %d steps of %d games"
          % (args.blocks, args.filters, args.games, lanes, args.sims, args.warmup, args.step_games))
-    barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
+    try:
+        barrier()   # also creates the RCCL communicator outside the timed region (matters when --warmup 0)
+    except Exception as exc:
+        if use_dist:
+            print(first_contact_hint("the first barrier (communicator creation)", exc, rank, world), file=sys.stderr, flush=True)
+        raise
     for i in range(args.warmup):
         t1 = time.time()
-        g, _ = step()
+        try:
+            g, _ = step()
+        except Exception as exc:
+            if use_dist and i == 0:   # the first exchange: counts all-gather + three padded all_gather_into_tensor
+                print(first_contact_hint("the first step's exchange", exc, rank, world), file=sys.stderr, flush=True)
+            raise
         tally_launches()
         beat("warm-up step %d/%d: %d games in %.2f s" % (i + 1, args.warmup, g, time.time() - t1))
     state["warming"] = False

@@ -106,3 +106,23 @@ def test_launcher_sigterm_ends_the_whole_stage_tree(tmp_path):
     finally:
         if launcher.poll() is None:
             launcher.kill()
+
+
+def test_first_contact_hint_names_the_knobs(monkeypatch):
+    """bench.py's N > 1 path has never met more than one RCCL rank; when its first contact fails (initialisation, the first
+    barrier, the first exchange) the operator is told what to flip first -- the IPC mode (and to which value), NCCL_DEBUG, the gloo
+    rehearsal -- instead of a bare traceback."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    t = b.first_contact_hint("the first barrier (communicator creation)", RuntimeError("hipIpcGetMemHandle: invalid argument"), 3, 8)
+    assert "rank 3/8" in t and "the first barrier" in t and "hipIpcGetMemHandle" in t
+    assert "HSA_ENABLE_IPC_MODE_LEGACY is 0 here" in t and "HSA_ENABLE_IPC_MODE_LEGACY=1 python bench.py --gpus 8" in t
+    assert "NCCL_DEBUG=INFO" in t and "OTHELLO_DIST_BACKEND=gloo" in t and "GPU_MAX_HW_QUEUES is 8" in t
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=0 python bench.py" in b.first_contact_hint("x", ValueError("y"), 0, 2)
+    src = open(BENCH).read()
+    assert src.count("first_contact_hint(") >= 4          # defined, and used at initialisation, the first barrier, the first exchange
