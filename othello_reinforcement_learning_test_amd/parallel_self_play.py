@@ -316,7 +316,8 @@ def create_parallel_self_play_worker(config, model, device=None, **kwargs):
     sp = config.get("self_play", {})
     # `self_play.continuous: true` -- a key of THIS package, absent from the reference's YAML files (absent = off = the
     # reference's call-by-call behaviour): the worker's slots keep playing between execute_episodes calls, so a trainer that
-    # asks for 100 episodes per iteration (configs/fast_8x8.yaml) is served from full slots instead of a ragged 100-game batch
+    # asks for 50-200 episodes per iteration (training.self_play_episodes_per_iter: 100 in configs/default_8x8.yaml, 50 in fast_8x8) is
+    # served from full slots instead of a ragged small batch
     # (INTEGRATION.md section 1 has the rates); the one semantic difference is that a game may span a weight update.
     # `self_play.stagger_rounds` spreads the slots' start over that many ply rounds.  A keyword argument of the same name wins.
     if "continuous" in sp:

@@ -360,7 +360,7 @@ def test_worker_continuous_mode_exact_with_cache_and_refresh(pkg):
 def test_continuous_mode_from_the_yaml_key(pkg):
     """`self_play.continuous: true` in the config dict create_parallel_self_play_worker takes (main.py:111-132 passes the YAML
     through; the key is this package's, absent = the reference's call-by-call worker): what a trainer that asks for 100
-    episodes per iteration (configs/fast_8x8.yaml) gets -- two successive execute_episodes(100) calls return >= 100 games
+    episodes per iteration (training.self_play_episodes_per_iter of configs/default_8x8.yaml) gets -- two successive execute_episodes(100) calls return >= 100 games
     each from slots that stay full, every game the oracle's game of the same id, tuple for tuple."""
     torch.manual_seed(9)
     net = pkg.OthelloResNet(2, 16).eval()
